@@ -17,7 +17,7 @@ DEV_HDR := $(wildcard raytracer_amd/csrc/*.h) include/mi355rt.h
 # -ffp-contract=off everywhere: the reference is Rust, which never fuses a*b+c.
 CXXFLAGS := -O2 -std=c++17 -fPIC -Wall -Wextra -ffp-contract=off -fno-fast-math
 HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -fno-fast-math \
-            -fgpu-rdc=0 -Wall -Wno-unused-function
+            -Wall -Wno-unused-function
 
 all: host device cli oracle
 

@@ -319,8 +319,12 @@ typedef struct rt_bvh_item {
   uint32_t rank;  /* tie-break rank: position in the reference's resolution order */
   uint32_t reserved;
 } rt_bvh_item;
-int rt_bvh_info(const rt_ctx* ctx, uint32_t* n_nodes, uint32_t* n_items, uint32_t* max_depth);
-int rt_bvh_copy(const rt_ctx* ctx, rt_bvh_node* nodes, rt_bvh_item* items);
+typedef struct rt_bvh rt_bvh;
+/* Host-only (needs no device): the same build rt_upload_scene performs. */
+int rt_bvh_build(const rt_scene* scene, rt_bvh** out);
+int rt_bvh_info(const rt_bvh* bvh, uint32_t* n_nodes, uint32_t* n_items, uint32_t* max_depth);
+int rt_bvh_copy(const rt_bvh* bvh, rt_bvh_node* nodes, rt_bvh_item* items);
+void rt_bvh_free(rt_bvh* bvh);
 
 const char* rt_last_error(const rt_ctx* ctx);
 void rt_destroy(rt_ctx* ctx);

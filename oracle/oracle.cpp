@@ -139,20 +139,25 @@ double powi5(double x) {  // compiler-rt __powidf2 / LLVM powi expansion: x * (x
 }
 
 Vec3 rand_unit_vector(const DrawCtx& d) {  // :35-47
-  for (uint32_t it = 0;; ++it) {
+  // the loop is capped like the device's (probability of reaching the cap: 2^-4000)
+  Vec3 v;
+  for (uint32_t it = 0; it < 4096; ++it) {
     double x, y, z;
     sym3(d.block(DRAW_SCATTER, it), x, y, z);
-    Vec3 v(x, y, z);
-    if (length_squared(v) < 1.0) return unit_vector(v);
+    v = Vec3(x, y, z);
+    if (length_squared(v) < 1.0) break;
   }
+  return unit_vector(v);
 }
 Vec3 rand_in_unit_disk(const DrawCtx& d) {  // :49-60
-  for (uint32_t it = 0;; ++it) {
+  Vec3 v;
+  for (uint32_t it = 0; it < 4096; ++it) {
     double x, y, z;
     sym3(d.block(DRAW_LENS, it), x, y, z);
-    Vec3 v(x, y, 0.0);
-    if (length_squared(v) < 1.0) return v;
+    v = Vec3(x, y, 0.0);
+    if (length_squared(v) < 1.0) break;
   }
+  return v;
 }
 
 // --------------------------------------------------------------------- Ray
@@ -1052,7 +1057,9 @@ OptHit flat_hit(const SceneData& sc, const FlatBvh& bvh, const Ray& ray, Range t
   if (bvh.n_nodes == 0) return best;
   double inv[3], noi[3];
   for (int a = 0; a < 3; ++a) {
+    // a zero component: huge finite reciprocal instead of inf, so lo*inv - o*inv is never inf - inf
     inv[a] = 1.0 / ray.direction[a];
+    if (!(std::fabs(inv[a]) <= 1e150)) inv[a] = std::copysign(1e150, ray.direction[a]);
     noi[a] = -(ray.origin[a] * inv[a]);
   }
   uint32_t stack[64];

@@ -1,0 +1,547 @@
+// Host side of rt_upload_scene: flattens an rt_scene into device records and
+// builds the acceleration structure.
+//
+// Two hierarchies are involved.  (1) The reference's own BVH
+// (BvhNode::new_along_axis, src/hittable/bvh.rs:33-77: stable median split on
+// box centroids, leaves below 256 objects) is rebuilt only for its ORDER: when
+// several objects are hit at exactly the same t the reference returns the one
+// its recursion prefers (right subtree over left, bvh.rs:93-97; first in a
+// leaf's list, hittable_list.rs:31), and that preference is handed to the
+// device as a per-item rank.  (2) The hierarchy the device walks is a binned-SAH
+// binary BVH over individual primitives with small leaves and 32-byte nodes
+// whose float boxes are rounded outwards; it only has to be conservative,
+// because the reference's result is "closest t over everything whose boxes
+// were passed" and its box test (src/geom/aabb.rs:35-50) never rejects a true
+// hit.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <limits>
+#include <numeric>
+
+#include "device_scene.h"
+#include "scene_validate.h"
+
+namespace rt {
+namespace {
+
+const double INF = std::numeric_limits<double>::infinity();
+
+struct Box {
+  double lo[3] = {INF, INF, INF};
+  double hi[3] = {-INF, -INF, -INF};
+  void grow(const double* p) {
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = std::fmin(lo[a], p[a]);
+      hi[a] = std::fmax(hi[a], p[a]);
+    }
+  }
+  void grow(const Box& b) {
+    grow(b.lo);
+    grow(b.hi);
+  }
+  double area() const {
+    double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    if (!(dx >= 0.0) || !(dy >= 0.0) || !(dz >= 0.0)) return 0.0;
+    return 2.0 * (dx * dy + dy * dz + dz * dx);
+  }
+};
+
+// ---- reference bounding boxes (for the rank order only) --------------------
+// Operation order follows the cited functions so that centroid keys, and with
+// them the stable sort, agree with the reference.
+
+Box aabb_new(const double* a, const double* b) {  // Aabb::new, src/geom/aabb.rs:16-21
+  Box r;
+  for (int i = 0; i < 3; ++i) {
+    r.lo[i] = std::fmin(a[i], b[i]);
+    r.hi[i] = std::fmax(a[i], b[i]);
+  }
+  return r;
+}
+
+void moving_center(const rt_prim& p, double time, double* c) {  // moving_sphere.rs:20-23
+  double portion = (p.time0 - time) / (p.time1 - p.time0);
+  for (int i = 0; i < 3; ++i) c[i] = (1.0 - portion) * p.center[i] + portion * p.center1[i];
+}
+
+Box ref_prim_box(const rt_prim& p, double t0, double t1) {
+  if (p.kind == RT_PRIM_SPHERE) {  // sphere.rs:67-72
+    double a[3], b[3];
+    for (int i = 0; i < 3; ++i) {
+      a[i] = p.center[i] + -p.radius;
+      b[i] = p.center[i] + p.radius;
+    }
+    return aabb_new(a, b);
+  }
+  if (p.kind == RT_PRIM_MOVING_SPHERE) {  // moving_sphere.rs:37-47
+    Box out;
+    for (double t : {t0, t1}) {
+      double c[3], a[3], b[3];
+      moving_center(p, t, c);
+      for (int i = 0; i < 3; ++i) {
+        a[i] = c[i] + -p.radius;
+        b[i] = c[i] + p.radius;
+      }
+      out.grow(aabb_new(a, b));
+    }
+    return out;
+  }
+  // rect.rs:20-34
+  double thickness = 0.001, w2 = p.width / 2.0, h2 = p.height / 2.0;
+  double off[3];
+  if (p.axis == 0) {
+    off[0] = thickness; off[1] = w2; off[2] = h2;
+  } else if (p.axis == 1) {
+    off[0] = w2; off[1] = thickness; off[2] = h2;
+  } else {
+    off[0] = w2; off[1] = h2; off[2] = thickness;
+  }
+  double a[3], b[3];
+  for (int i = 0; i < 3; ++i) {
+    a[i] = p.center[i] + -off[i];
+    b[i] = p.center[i] + off[i];
+  }
+  return aabb_new(a, b);
+}
+
+Box apply_op_box(const rt_op& op, const Box& in) {
+  if (op.kind == RT_OP_TRANSLATE) {  // instance.rs:21-25
+    double a[3], b[3];
+    for (int i = 0; i < 3; ++i) {
+      a[i] = in.lo[i] + op.a[i];
+      b[i] = in.hi[i] + op.a[i];
+    }
+    return aabb_new(a, b);
+  }
+  // RotateY::bounding_box, instance.rs:85-101: rotate the 8 corners back to the outer frame
+  double s = op.a[0], c = op.a[1];
+  Box out;
+  const double xs[2] = {in.lo[0], in.hi[0]}, ys[2] = {in.lo[1], in.hi[1]},
+               zs[2] = {in.lo[2], in.hi[2]};
+  for (double x : xs)
+    for (double y : ys)
+      for (double z : zs) {
+        double p[3] = {c * x + s * z, y, -s * x + c * z};
+        out.grow(p);
+      }
+  return out;
+}
+
+Box ref_object_box(const rt_scene& s, const rt_object& o, double t0, double t1) {
+  Box b;
+  if (o.is_cuboid) {  // cuboid.rs:45-47
+    double lo[3], hi[3];
+    for (int i = 0; i < 3; ++i) {
+      lo[i] = o.cuboid_center[i] + -o.cuboid_half[i];
+      hi[i] = o.cuboid_center[i] + o.cuboid_half[i];
+    }
+    b = aabb_new(lo, hi);
+  } else {
+    for (uint32_t k = 0; k < o.prim_count; ++k) b.grow(ref_prim_box(s.prims[o.first_prim + k], t0, t1));
+  }
+  for (uint32_t k = o.inner_op_count; k-- > 0;) b = apply_op_box(s.ops[o.inner_first_op + k], b);
+  // ConstantMedium::bounding_box is its boundary's (constant_medium.rs:78-80)
+  for (uint32_t k = o.op_count; k-- > 0;) b = apply_op_box(s.ops[o.first_op + k], b);
+  return b;
+}
+
+// OrderedFloat order: NaN greatest.
+bool of_less(double a, double b) {
+  if (std::isnan(a)) return false;
+  if (std::isnan(b)) return true;
+  return a < b;
+}
+
+// Objects in the order the reference prefers among equal-t hits.
+void reference_order(const std::vector<Box>& boxes, std::vector<uint32_t>& ids, int axis,
+                     std::vector<uint32_t>& out) {
+  const size_t kMaxPerLeaf = 256;  // bvh.rs:9
+  if (ids.size() < kMaxPerLeaf) {
+    out.insert(out.end(), ids.begin(), ids.end());
+    return;
+  }
+  std::stable_sort(ids.begin(), ids.end(), [&](uint32_t a, uint32_t b) {
+    double ka = (boxes[a].lo[axis] + boxes[a].hi[axis]) / 2.0;
+    double kb = (boxes[b].lo[axis] + boxes[b].hi[axis]) / 2.0;
+    return of_less(ka, kb);
+  });
+  size_t half = ids.size() / 2;
+  std::vector<uint32_t> left(ids.begin(), ids.begin() + (long)half);
+  std::vector<uint32_t> right(ids.begin() + (long)half, ids.end());
+  int next = (axis + 1) % 3;
+  reference_order(boxes, right, next, out);  // the right subtree wins ties
+  reference_order(boxes, left, next, out);
+}
+
+// ---- true (conservative) boxes for the device hierarchy ---------------------
+
+Box true_prim_box(const rt_prim& p, double t0, double t1) {
+  Box b;
+  if (p.kind == RT_PRIM_SPHERE) {
+    double r = std::fabs(p.radius);
+    for (int i = 0; i < 3; ++i) {
+      b.lo[i] = p.center[i] - r;
+      b.hi[i] = p.center[i] + r;
+    }
+    return b;
+  }
+  if (p.kind == RT_PRIM_MOVING_SPHERE) {
+    // the centre is affine in time, so the two ends of the shutter bound it
+    double r = std::fabs(p.radius);
+    for (double t : {t0, t1}) {
+      double c[3];
+      moving_center(p, t, c);
+      double lo[3], hi[3];
+      for (int i = 0; i < 3; ++i) {
+        lo[i] = c[i] - r;
+        hi[i] = c[i] + r;
+      }
+      b.grow(lo);
+      b.grow(hi);
+    }
+    return b;
+  }
+  return ref_prim_box(p, t0, t1);  // the rect's padded box contains its extent
+}
+
+// Outward float rounding with a relative pad: the slab test runs on these
+// values in higher precision than they are stored in, so the pad, not the
+// arithmetic, is what keeps it conservative.
+void store_box(const Box& b, rt_bvh_node& n) {
+  for (int a = 0; a < 3; ++a) {
+    double lo = b.lo[a], hi = b.hi[a];
+    if (!(lo <= hi)) {  // empty or NaN: never cull
+      n.lo[a] = -FLT_MAX;
+      n.hi[a] = FLT_MAX;
+      continue;
+    }
+    double scale = std::fmax(std::fmax(std::fabs(lo), std::fabs(hi)), hi - lo);
+    double pad = scale * (1.0 / 1048576.0) + 1e-30;
+    double l = lo - pad, h = hi + pad;
+    float fl = (float)l, fh = (float)h;
+    if ((double)fl > l) fl = std::nextafterf(fl, -FLT_MAX);
+    if ((double)fh < h) fh = std::nextafterf(fh, FLT_MAX);
+    if (!std::isfinite(fl)) fl = -FLT_MAX;
+    if (!std::isfinite(fh)) fh = FLT_MAX;
+    n.lo[a] = fl;
+    n.hi[a] = fh;
+  }
+}
+
+struct BuildItem {
+  Box box;
+  double centroid[3];
+  uint32_t slot;  // index into the pre-order item list
+};
+
+struct Builder {
+  std::vector<BuildItem>& items;
+  std::vector<rt_bvh_node>& nodes;
+  std::vector<uint32_t>& leaf_order;  // slots in leaf order
+  uint32_t max_depth = 0;
+
+  Builder(std::vector<BuildItem>& i, std::vector<rt_bvh_node>& n, std::vector<uint32_t>& lo)
+      : items(i), nodes(n), leaf_order(lo) {}
+
+  // Can `count` items still be split into leaves within `levels` more interior levels?
+  static bool fits(uint64_t count, uint32_t levels) {
+    if (levels >= 40) return true;
+    return count <= ((uint64_t)kMaxLeafItems << levels);
+  }
+
+  void build(uint32_t node_index, size_t begin, size_t end, uint32_t depth) {
+    max_depth = std::max(max_depth, depth);
+    Box bounds, cbounds;
+    for (size_t i = begin; i < end; ++i) {
+      bounds.grow(items[i].box);
+      cbounds.grow(items[i].centroid);
+    }
+    store_box(bounds, nodes[node_index]);
+    size_t count = end - begin;
+    if (count <= kMaxLeafItems) {
+      nodes[node_index].a = (uint32_t)leaf_order.size();
+      nodes[node_index].b = (uint32_t)count;
+      for (size_t i = begin; i < end; ++i) leaf_order.push_back(items[i].slot);
+      return;
+    }
+    uint32_t levels_left = kMaxBvhDepth - depth - 1;  // levels available to each child
+    int axis = 0;
+    size_t mid = begin;
+    bool have_split = false;
+
+    // binned SAH on the axis/plane with the lowest cost
+    const int kBins = 16;
+    double best_cost = INF;
+    int best_axis = -1, best_plane = -1;
+    for (int a = 0; a < 3; ++a) {
+      double lo = cbounds.lo[a], hi = cbounds.hi[a];
+      if (!(hi > lo) || !std::isfinite(lo) || !std::isfinite(hi)) continue;
+      Box bin_box[kBins];
+      size_t bin_count[kBins] = {0};
+      double scale = (double)kBins / (hi - lo);
+      for (size_t i = begin; i < end; ++i) {
+        int b = (int)((items[i].centroid[a] - lo) * scale);
+        b = std::min(std::max(b, 0), kBins - 1);
+        bin_box[b].grow(items[i].box);
+        bin_count[b]++;
+      }
+      double right_area[kBins];
+      size_t right_count[kBins];
+      Box acc;
+      size_t cnt = 0;
+      for (int b = kBins - 1; b > 0; --b) {
+        acc.grow(bin_box[b]);
+        cnt += bin_count[b];
+        right_area[b] = acc.area();
+        right_count[b] = cnt;
+      }
+      Box lacc;
+      size_t lcnt = 0;
+      for (int b = 0; b < kBins - 1; ++b) {
+        lacc.grow(bin_box[b]);
+        lcnt += bin_count[b];
+        size_t rcnt = right_count[b + 1];
+        if (lcnt == 0 || rcnt == 0) continue;
+        if (!fits(lcnt, levels_left) || !fits(rcnt, levels_left)) continue;
+        double cost = lacc.area() * (double)lcnt + right_area[b + 1] * (double)rcnt;
+        if (cost < best_cost) {
+          best_cost = cost;
+          best_axis = a;
+          best_plane = b;
+        }
+      }
+    }
+    if (best_axis >= 0) {
+      axis = best_axis;
+      double lo = cbounds.lo[axis], hi = cbounds.hi[axis];
+      double scale = (double)kBins / (hi - lo);
+      auto it = std::partition(items.begin() + (long)begin, items.begin() + (long)end,
+                               [&](const BuildItem& bi) {
+                                 int b = (int)((bi.centroid[axis] - lo) * scale);
+                                 b = std::min(std::max(b, 0), kBins - 1);
+                                 return b <= best_plane;
+                               });
+      mid = (size_t)(it - items.begin());
+      have_split = mid > begin && mid < end;
+    }
+    if (!have_split) {
+      // median split on the widest centroid axis: always balanced, so the depth bound holds
+      double widest = -1.0;
+      for (int a = 0; a < 3; ++a) {
+        double ext = cbounds.hi[a] - cbounds.lo[a];
+        if (ext > widest) {
+          widest = ext;
+          axis = a;
+        }
+      }
+      mid = begin + count / 2;
+      std::nth_element(items.begin() + (long)begin, items.begin() + (long)mid,
+                       items.begin() + (long)end, [&](const BuildItem& x, const BuildItem& y) {
+                         return x.centroid[axis] < y.centroid[axis];
+                       });
+    }
+    uint32_t left = (uint32_t)nodes.size();
+    nodes.emplace_back();
+    nodes.emplace_back();
+    nodes[node_index].a = left;
+    nodes[node_index].b = 0x80000000u | (uint32_t)axis;
+    build(left, begin, mid, depth + 1);
+    build(left + 1, mid, end, depth + 1);
+  }
+};
+
+uint32_t pack_ops(uint32_t first, uint32_t count) { return (first & 0x00FFFFFFu) | (count << 24); }
+
+}  // namespace
+
+std::string flatten_scene(const rt_scene& s, FlatScene& out, int& code) {
+  code = RT_ERR_INVALID;
+  std::string bad = validate_scene(s);
+  if (!bad.empty()) return "invalid scene: " + bad;
+  if (s.n_ops >= (1u << 24)) {
+    code = RT_ERR_LIMIT;
+    return "too many instance ops (limit 16777215)";
+  }
+  out = FlatScene();
+  out.camera = s.camera;
+  std::memcpy(out.background, s.background, sizeof out.background);
+  const double t0 = s.camera.time0, t1 = s.camera.time1;
+
+  // textures, materials, tables
+  out.textures.resize(s.n_textures);
+  std::vector<uint8_t> tex_needs_uv(s.n_textures, 0);
+  for (uint32_t i = 0; i < s.n_textures; ++i) {
+    const rt_texture& t = s.textures[i];
+    DTexture d{};
+    d.kind = t.kind;
+    d.a = t.a;
+    d.b = t.b;
+    std::memcpy(d.color, t.color, sizeof d.color);
+    d.scale = t.scale;
+    out.textures[i] = d;
+    // children precede parents (validated), so one forward pass settles the flag
+    if (t.kind == RT_TEX_IMAGE) tex_needs_uv[i] = 1;
+    if (t.kind == RT_TEX_CHECKER) tex_needs_uv[i] = tex_needs_uv[t.a] | tex_needs_uv[t.b];
+  }
+  out.materials.resize(s.n_materials);
+  for (uint32_t i = 0; i < s.n_materials; ++i) {
+    const rt_material& m = s.materials[i];
+    DMaterial d{};
+    d.kind = m.kind;
+    d.texture = m.texture;
+    std::memcpy(d.albedo, m.albedo, sizeof d.albedo);
+    d.param = m.param;
+    bool textured = m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_DIFFUSE_LIGHT ||
+                    m.kind == RT_MAT_ISOTROPIC;
+    d.needs_uv = textured ? tex_needs_uv[m.texture] : 0;
+    out.materials[i] = d;
+  }
+  out.perlin.assign(s.perlin, s.perlin + s.n_perlin);
+  out.images.resize(s.n_images);
+  for (uint32_t i = 0; i < s.n_images; ++i)
+    out.images[i] = DImage{s.images[i].width, s.images[i].height, s.images[i].offset};
+  out.texels.assign(s.texels, s.texels + s.n_texel_bytes);
+  out.ops.resize(s.n_ops);
+  for (uint32_t i = 0; i < s.n_ops; ++i) {
+    DOp d{};
+    d.kind = s.ops[i].kind;
+    std::memcpy(d.a, s.ops[i].a, sizeof d.a);
+    out.ops[i] = d;
+  }
+
+  // reference preference order -> rank of the first primitive of every object
+  std::vector<Box> ref_boxes(s.n_objects);
+  for (uint32_t i = 0; i < s.n_objects; ++i) ref_boxes[i] = ref_object_box(s, s.objects[i], t0, t1);
+  std::vector<uint32_t> ids(s.n_objects), order;
+  std::iota(ids.begin(), ids.end(), 0u);
+  order.reserve(s.n_objects);
+  reference_order(ref_boxes, ids, 0, order);
+  std::vector<uint32_t> rank_base(s.n_objects, 0);
+  {
+    uint64_t running = 0;
+    for (uint32_t obj : order) {
+      rank_base[obj] = (uint32_t)running;
+      running += s.objects[obj].prim_count;
+      if (running >= 0xFFFFFFFFull) {
+        code = RT_ERR_LIMIT;
+        return "too many primitives";
+      }
+    }
+  }
+
+  auto make_record = [&](const rt_prim& p, uint32_t ops_word, uint32_t object) {
+    DPrim d{};
+    const rt_material& m = s.materials[p.material];
+    uint32_t needs_uv = out.materials[p.material].needs_uv ? 1u : 0u;
+    d.material = p.material;
+    d.object = object;
+    d.ops = ops_word;
+    if (p.kind == RT_PRIM_SPHERE) {
+      d.kind = DP_SPHERE;
+      d.p[0] = p.center[0];
+      d.p[1] = p.center[1];
+      d.p[2] = p.center[2];
+      d.p[3] = p.radius;
+    } else if (p.kind == RT_PRIM_MOVING_SPHERE) {
+      d.kind = DP_MOVING_SPHERE;
+      d.p[0] = p.center[0];
+      d.p[1] = p.center[1];
+      d.p[2] = p.center[2];
+      d.p[3] = p.radius;
+      d.p[4] = p.time0;
+      d.p[5] = (double)out.aux.size();
+      out.aux.push_back(DAux{{p.center1[0], p.center1[1], p.center1[2], p.time1}});
+    } else {
+      d.kind = DP_RECT | (p.axis << 4);
+      Box b = ref_prim_box(p, 0.0, 0.0);  // AxisAlignedRect::bounding_box, rect.rs:20-34
+      int d0 = (int)p.axis, d1 = (d0 + 1) % 3, d2 = (d1 + 1) % 3;
+      d.p[0] = p.center[d0];
+      d.p[1] = b.lo[d1];
+      d.p[2] = b.hi[d1];
+      d.p[3] = b.lo[d2];
+      d.p[4] = b.hi[d2];
+    }
+    d.kind |= (m.kind & 7u) << 8;
+    d.kind |= needs_uv << 11;
+    return d;
+  };
+
+  // leaf slots in pre-order (object order), then the SAH build permutes them
+  std::vector<DPrim> slots;
+  std::vector<rt_bvh_item> slot_items;
+  std::vector<BuildItem> build_items;
+  for (uint32_t oi = 0; oi < s.n_objects; ++oi) {
+    const rt_object& o = s.objects[oi];
+    auto through_ops = [&](Box b) {
+      for (uint32_t k = o.inner_op_count; k-- > 0;) b = apply_op_box(s.ops[o.inner_first_op + k], b);
+      for (uint32_t k = o.op_count; k-- > 0;) b = apply_op_box(s.ops[o.first_op + k], b);
+      return b;
+    };
+    if (o.is_medium) {
+      out.has_media = true;
+      DPrim d{};
+      d.kind = DP_MEDIUM | ((uint32_t)RT_MAT_ISOTROPIC << 8);
+      d.kind |= (out.materials[o.medium_material].needs_uv ? 1u : 0u) << 11;
+      d.ops = pack_ops(o.first_op, o.op_count);
+      d.material = o.medium_material;
+      d.object = oi;
+      d.p[0] = o.neg_inv_density;
+      d.p[1] = (double)out.boundary.size();
+      d.p[2] = (double)o.prim_count;
+      Box b;
+      for (uint32_t k = 0; k < o.prim_count; ++k) {
+        const rt_prim& p = s.prims[o.first_prim + k];
+        out.boundary.push_back(make_record(p, pack_ops(o.inner_first_op, o.inner_op_count), oi));
+        b.grow(true_prim_box(p, t0, t1));
+      }
+      BuildItem bi;
+      bi.box = through_ops(b);
+      bi.slot = (uint32_t)slots.size();
+      build_items.push_back(bi);
+      slots.push_back(d);
+      slot_items.push_back(rt_bvh_item{oi, kNoPrim, rank_base[oi], 0});
+    } else {
+      for (uint32_t k = 0; k < o.prim_count; ++k) {
+        const rt_prim& p = s.prims[o.first_prim + k];
+        BuildItem bi;
+        bi.box = through_ops(true_prim_box(p, t0, t1));
+        bi.slot = (uint32_t)slots.size();
+        build_items.push_back(bi);
+        slots.push_back(make_record(p, pack_ops(o.first_op, o.op_count), oi));
+        slot_items.push_back(rt_bvh_item{oi, o.first_prim + k, rank_base[oi] + k, 0});
+      }
+    }
+  }
+  for (BuildItem& bi : build_items)
+    for (int a = 0; a < 3; ++a) {
+      double c = 0.5 * bi.box.lo[a] + 0.5 * bi.box.hi[a];
+      bi.centroid[a] = std::isfinite(c) ? c : 0.0;
+    }
+
+  if (!build_items.empty()) {
+    out.nodes.reserve(build_items.size() * 2);
+    out.nodes.emplace_back();
+    std::vector<uint32_t> leaf_order;
+    leaf_order.reserve(build_items.size());
+    Builder b(build_items, out.nodes, leaf_order);
+    b.build(0, 0, build_items.size(), 0);
+    out.bvh_depth = b.max_depth;
+    out.prims.reserve(leaf_order.size());
+    for (uint32_t slot : leaf_order) {
+      out.prims.push_back(slots[slot]);
+      out.items.push_back(slot_items[slot]);
+      out.ranks.push_back(slot_items[slot].rank);
+    }
+  }
+  if (out.bvh_depth > kMaxBvhDepth) {
+    code = RT_ERR_LIMIT;
+    return "acceleration structure deeper than the traversal stack";
+  }
+  code = RT_OK;
+  return "";
+}
+
+}  // namespace rt

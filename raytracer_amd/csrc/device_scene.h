@@ -1,0 +1,102 @@
+// Records the device kernels read, and the host-side flattening of an rt_scene
+// into them.  Layout rules: every record is a multiple of 16 bytes and is read
+// with 16-byte vector loads; f64 parameters are stored exactly as the reference
+// would compute them on the host, so the device repeats only per-ray arithmetic.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/mi355rt.h"
+
+namespace rt {
+
+enum DPrimKind : uint32_t {
+  DP_SPHERE = 0,
+  DP_MOVING_SPHERE = 1,
+  DP_RECT = 2,
+  DP_MEDIUM = 3
+};
+
+// 64-byte primitive record.
+//   kind word: bits 0-3 DPrimKind, bits 4-5 rect axis, bits 8-10 material kind
+//              (rt_material_kind) of `material`, bit 11 "texture needs (u,v)".
+//   ops word : first op (low 24 bits) | op count (high 8 bits), outermost first.
+//   sphere        p = {cx, cy, cz, radius, -, -}
+//   moving sphere p = {c0x, c0y, c0z, radius, time0, aux index}; aux = {c1x, c1y, c1z, time1}
+//   rect          p = {center[axis], min[d1], max[d1], min[d2], max[d2], -}
+//                 (d1 = axis.next(), d2 = d1.next(); min/max as rect.rs:20-34 computes them)
+//   medium        p = {neg_inv_density, first boundary prim, boundary prim count, -, -, -}
+struct DPrim {
+  double p[6];
+  uint32_t kind;
+  uint32_t ops;
+  uint32_t material;
+  uint32_t object;
+};
+static_assert(sizeof(DPrim) == 64, "DPrim must be 64 bytes");
+
+struct DOp {  // 32 bytes
+  uint32_t kind;  // rt_op_kind
+  uint32_t pad;
+  double a[3];    // translate: offset; rotate_y: sin, cos
+};
+static_assert(sizeof(DOp) == 32, "DOp must be 32 bytes");
+
+struct DAux {  // 32 bytes
+  double v[4];
+};
+
+struct DMaterial {  // 48 bytes
+  uint32_t kind;
+  uint32_t texture;
+  double albedo[3];
+  double param;
+  uint32_t needs_uv;
+  uint32_t pad;
+};
+static_assert(sizeof(DMaterial) == 48, "DMaterial must be 48 bytes");
+
+struct DTexture {  // 48 bytes
+  uint32_t kind;
+  uint32_t a, b;
+  uint32_t pad;
+  double color[3];
+  double scale;
+};
+static_assert(sizeof(DTexture) == 48, "DTexture must be 48 bytes");
+
+struct DImage {  // 16 bytes
+  uint32_t width, height;
+  uint64_t offset;
+};
+
+const uint32_t kMaxBvhDepth = 32;   // interior levels; bounds the traversal stack
+const uint32_t kMaxLeafItems = 4;
+const uint32_t kNoPrim = 0xFFFFFFFFu;
+
+// Everything the device needs, still in host memory.
+struct FlatScene {
+  std::vector<rt_bvh_node> nodes;
+  std::vector<rt_bvh_item> items;   // one per leaf slot, same order as prims
+  std::vector<DPrim> prims;         // leaf slots
+  std::vector<uint32_t> ranks;      // tie-break rank per leaf slot
+  std::vector<DPrim> boundary;      // boundary primitives of constant media
+  std::vector<DOp> ops;
+  std::vector<DAux> aux;
+  std::vector<DMaterial> materials;
+  std::vector<DTexture> textures;
+  std::vector<rt_perlin> perlin;
+  std::vector<DImage> images;
+  std::vector<uint8_t> texels;
+  rt_camera camera{};
+  double background[3] = {0, 0, 0};
+  uint32_t bvh_depth = 0;
+  bool has_media = false;
+};
+
+// Flatten + build.  Returns "" on success, else an error message; `code`
+// receives the rt_status to report.
+std::string flatten_scene(const rt_scene& scene, FlatScene& out, int& code);
+
+}  // namespace rt

@@ -1,0 +1,777 @@
+// The HIP render path and its C ABI (rt_* in include/mi355rt.h).
+//
+// Wavefront organisation of the reference's render closure (src/main.rs:82-101):
+// a pass takes S samples of every pixel of the window as independent paths
+// (path = s_local * n_pixels + pixel, so a wave holds neighbouring pixels of one
+// sample).  Per pass:
+//   raygen   jitter + Camera::get_ray                    (main.rs:87-94, camera.rs:22-36)
+//   repeat max_depth times (ray_color's recursion, main.rs:120-140, unrolled):
+//     extend   closest hit over the BVH, then each live path is appended to the
+//              bin of what it hit: miss, or one bin per material kind
+//     shade    walks the bins in order, so a wave shades one material kind:
+//              emitted, scatter, attenuation; surviving paths are appended to
+//              the next bounce's live queue
+//   resolve  per pixel, adds the S path radiances in sample order (main.rs:97)
+// Queue appends use one atomic per wave (ballot + popcount).  All queue sizes
+// live in device memory, so a pass runs without a host round trip.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "rt_device.h"
+
+using namespace rt;
+
+namespace {
+
+const int kBlock = 256;
+const uint32_t kBins = 1 + RT_MAT_KINDS;  // miss + one per material kind
+const uint32_t kCounterStride = 8;        // [0..5] bin sizes, [6] next live count
+
+struct PathBuffers {
+  double4* ray_o;     // origin xyz, time
+  double4* ray_d;     // direction xyz, hit t (written by extend)
+  double4* beta;      // running attenuation product
+  double4* radiance;  // running radiance
+  uint32_t* hit_item; // leaf slot hit, or kNoPrim
+  uint32_t* live[2];  // live-path queues, ping-pong
+  uint32_t* bins;     // kBins queues of `capacity` entries
+  uint32_t* counters; // (max_depth) x kCounterStride
+  uint64_t capacity;
+};
+
+struct PassInfo {
+  uint32_t width, height;      // full image
+  uint32_t x0, y0, ww, wh;     // window
+  uint32_t n_pixels;           // ww * wh
+  uint32_t n_paths;            // n_pixels * samples in this pass
+  uint32_t sample_base;        // absolute index of the pass's first sample
+  uint32_t first_pass;         // 1: resolve starts the sums
+  uint32_t samples;            // samples per pixel in this pass
+  uint64_t seed;
+};
+
+RT_DEV uint32_t lane_id() { return __lane_id(); }
+
+// Slot for each active lane in a queue, one atomic per wave.  Must be reached by
+// whole waves; `active` selects the lanes that append.
+RT_DEV uint32_t wave_append(uint32_t* counter, bool active) {
+  unsigned long long mask = __ballot(active);
+  uint32_t base = 0;
+  if (mask != 0ull) {
+    uint32_t lane = lane_id();
+    uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, (int)leader);
+    base += (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+  }
+  return base;
+}
+
+RT_DEV void flush_stats(const Stats& st, unsigned long long* g) {
+#pragma unroll
+  for (int i = 0; i < RT_STAT_COUNT; ++i)
+    if (st.v[i]) atomicAdd(g + i, (unsigned long long)st.v[i]);
+}
+
+// --------------------------------------------------------------- raygen
+__global__ void __launch_bounds__(kBlock)
+raygen_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps) {
+  uint32_t path = blockIdx.x * kBlock + threadIdx.x;
+  if (path >= ps.n_paths) return;
+  uint32_t local = path % ps.n_pixels, s_local = path / ps.n_pixels;
+  uint32_t x = ps.x0 + local % ps.ww, y = ps.y0 + local / ps.ww;
+  DrawKey key{ps.seed, y * ps.width + x, ps.sample_base + s_local, 0u};
+  u32x4 j = draw(key, DRAW_JITTER, 0);
+  double jx = u01_53(j.x, j.y), jy = u01_53(j.z, j.w);
+  // main.rs:91-93
+  double u = ((double)x + jx) / ((double)ps.width - 1.0);
+  double v = ((double)(ps.height - y) + jy) / ((double)ps.height - 1.0);
+  // Camera::get_ray, camera.rs:22-36
+  const rt_camera& c = sc.cam;
+  V3 rd = vscale(rand_in_unit_disk(key), c.lens_radius);
+  V3 offset = vadd(vscale(v3(c.u), rd.x), vscale(v3(c.v), rd.y));
+  double time;
+  if (c.time1 > c.time0) {
+    u32x4 tb = draw(key, DRAW_TIME, 0);
+    time = c.time0 + (c.time1 - c.time0) * u01_53(tb.x, tb.y);
+  } else {
+    time = c.time0;
+  }
+  V3 origin = vadd(v3(c.origin), offset);
+  V3 dir = vsub(vsub(vadd(vadd(v3(c.lower_left), vscale(v3(c.horizontal), u)),
+                          vscale(v3(c.vertical), v)),
+                     v3(c.origin)),
+                offset);
+  pb.ray_o[path] = make_double4(origin.x, origin.y, origin.z, time);
+  pb.ray_d[path] = make_double4(dir.x, dir.y, dir.z, 0.0);
+  pb.beta[path] = make_double4(1.0, 1.0, 1.0, 0.0);
+  pb.radiance[path] = make_double4(0.0, 0.0, 0.0, 0.0);
+}
+
+// --------------------------------------------------------------- extend
+template <bool STATS, bool MEDIA>
+__global__ void __launch_bounds__(kBlock)
+extend_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps, uint32_t bounce,
+              unsigned long long* g_stats) {
+  __shared__ uint32_t s_stack[kMaxBvhDepth * kBlock];
+  const uint32_t* live = pb.live[bounce & 1u];
+  uint32_t* counters = pb.counters + (size_t)bounce * kCounterStride;
+  const uint32_t n_live =
+      bounce == 0 ? ps.n_paths : pb.counters[(size_t)(bounce - 1) * kCounterStride + 6];
+  Stats st;
+  if (STATS) st.clear();
+  const uint32_t stride = gridDim.x * kBlock;
+  // the loop bound is rounded up to whole waves so that every lane reaches the ballots
+  for (uint32_t base = blockIdx.x * kBlock; base < n_live; base += stride) {
+    uint32_t i = base + threadIdx.x;
+    bool valid = i < n_live;
+    uint32_t path = 0, bin = 0;
+    if (valid) {
+      path = bounce == 0 ? i : live[i];
+      double4 ro = pb.ray_o[path];
+      double4 rdv = pb.ray_d[path];
+      uint32_t s_local = path / ps.n_pixels, local = path % ps.n_pixels;
+      uint32_t x = ps.x0 + local % ps.ww, y = ps.y0 + local / ps.ww;
+      DrawKey key{ps.seed, y * ps.width + x, ps.sample_base + s_local, bounce};
+      stat<STATS>(st, RT_STAT_RAYS);
+      Closest h = closest_hit<STATS, MEDIA>(sc, v3(ro.x, ro.y, ro.z), v3(rdv.x, rdv.y, rdv.z), ro.w,
+                                            0.001, key, s_stack + threadIdx.x, kBlock, st);
+      pb.hit_item[path] = h.item;
+      if (h.item != kNoPrim) {
+        pb.ray_d[path].w = h.t;
+        bin = 1u + ((sc.prims[h.item].kind >> 8) & 7u);
+        stat<STATS>(st, RT_STAT_HITS);
+      }
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < kBins; ++k) {
+      bool mine = valid && bin == k;
+      uint32_t slot = wave_append(counters + k, mine);
+      if (mine) pb.bins[(size_t)k * pb.capacity + slot] = path;
+    }
+  }
+  if (STATS) flush_stats(st, g_stats);
+}
+
+// ---------------------------------------------------------------- shade
+template <bool STATS>
+__global__ void __launch_bounds__(kBlock)
+shade_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps, uint32_t bounce, uint32_t max_depth,
+             unsigned long long* g_stats) {
+  uint32_t* counters = pb.counters + (size_t)bounce * kCounterStride;
+  uint32_t* next_live = pb.live[(bounce + 1u) & 1u];
+  uint32_t prefix[kBins + 1];
+  prefix[0] = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < kBins; ++k) prefix[k + 1] = prefix[k] + counters[k];
+  const uint32_t total = prefix[kBins];
+  Stats st;
+  if (STATS) st.clear();
+  const uint32_t stride = gridDim.x * kBlock;
+  for (uint32_t base = blockIdx.x * kBlock; base < total; base += stride) {
+    uint32_t i = base + threadIdx.x;
+    bool valid = i < total;
+    bool survives = false;
+    uint32_t path = 0;
+    if (valid) {
+      uint32_t bin = 0;
+#pragma unroll
+      for (uint32_t k = 1; k < kBins; ++k) bin += i >= prefix[k] ? 1u : 0u;
+      path = pb.bins[(size_t)bin * pb.capacity + (i - prefix[bin])];
+      double4 bt = pb.beta[path];
+      V3 beta = v3(bt.x, bt.y, bt.z);
+      if (bin == 0) {
+        // miss: the recursion returns `background` (main.rs:137-139)
+        stat<STATS>(st, RT_STAT_SHADE_MISS);
+        double4 L = pb.radiance[path];
+        V3 add = vmul(beta, v3(sc.bg));
+        pb.radiance[path] = make_double4(L.x + add.x, L.y + add.y, L.z + add.z, 0.0);
+      } else {
+        stat<STATS>(st, RT_STAT_SHADE_LAMBERTIAN + (int)(bin - 1u));
+        double4 ro = pb.ray_o[path];
+        double4 rdv = pb.ray_d[path];
+        V3 o = v3(ro.x, ro.y, ro.z), d = v3(rdv.x, rdv.y, rdv.z);
+        double time = ro.w, t = rdv.w;
+        const DPrim pr = sc.prims[pb.hit_item[path]];
+        const DMaterial m = sc.materials[pr.material];
+        bool want_uv = (pr.kind >> 11) & 1u;
+        Record rec = make_record(sc, pr, o, d, time, t, want_uv);
+        uint32_t s_local = path / ps.n_pixels, local = path % ps.n_pixels;
+        uint32_t x = ps.x0 + local % ps.ww, y = ps.y0 + local / ps.ww;
+        DrawKey key{ps.seed, y * ps.width + x, ps.sample_base + s_local, bounce};
+        V3 attenuation = v3(0.0, 0.0, 0.0), dir = v3(0.0, 0.0, 0.0);
+        bool scattered = false;
+        const uint32_t kind = bin - 1u;
+        if (kind == RT_MAT_LAMBERTIAN) {  // lambertian.rs:13-25
+          dir = vadd(rec.normal, rand_unit_vector(key));
+          if (vnear_zero(dir)) dir = rec.normal;
+          attenuation = texture_value<STATS>(sc, m.texture, rec.u, rec.v, rec.p, st);
+          scattered = true;
+        } else if (kind == RT_MAT_METAL) {  // metal.rs:12-28
+          V3 reflected = vreflect(vunit(d), rec.normal);
+          if (vdot(reflected, rec.normal) > 0.0) {
+            dir = vadd(reflected, vscale(rand_unit_vector(key), m.param));
+            scattered = true;
+          }
+          attenuation = v3(m.albedo);
+        } else if (kind == RT_MAT_DIELECTRIC) {  // dielectric.rs:14-38
+          double ratio = rec.front ? 1.0 / m.param : m.param;
+          V3 ud = vunit(d);
+          double cos_theta = fmin(vdot(vneg(ud), rec.normal), 1.0);
+          double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
+          bool cannot_refract = ratio * sin_theta > 1.0;
+          u32x4 fb = draw(key, DRAW_FRESNEL, 0);
+          bool should_reflect = reflectance(cos_theta, ratio) > u01_53(fb.x, fb.y);
+          dir = (cannot_refract || should_reflect) ? vreflect(ud, rec.normal)
+                                                   : vrefract(ud, rec.normal, ratio);
+          attenuation = v3(1.0, 1.0, 1.0);
+          scattered = true;
+        } else if (kind == RT_MAT_DIFFUSE_LIGHT) {  // emissive.rs:10-12; never scatters
+          V3 emitted = texture_value<STATS>(sc, m.texture, rec.u, rec.v, rec.p, st);
+          double4 L = pb.radiance[path];
+          V3 add = vmul(beta, emitted);
+          pb.radiance[path] = make_double4(L.x + add.x, L.y + add.y, L.z + add.z, 0.0);
+        } else {  // isotropic.rs:10-17
+          attenuation = texture_value<STATS>(sc, m.texture, rec.u, rec.v, rec.p, st);
+          dir = rand_unit_vector(key);
+          scattered = true;
+        }
+        // depth budget: the scattered ray of the last allowed hit returns black (main.rs:121-122)
+        if (scattered && bounce + 1u < max_depth) {
+          survives = true;
+          V3 nb = vmul(beta, attenuation);
+          pb.beta[path] = make_double4(nb.x, nb.y, nb.z, 0.0);
+          pb.ray_o[path] = make_double4(rec.p.x, rec.p.y, rec.p.z, time);
+          pb.ray_d[path] = make_double4(dir.x, dir.y, dir.z, 0.0);
+        }
+      }
+    }
+    uint32_t slot = wave_append(counters + 6, survives);
+    if (survives) next_live[slot] = path;
+  }
+  if (STATS) flush_stats(st, g_stats);
+}
+
+// -------------------------------------------------------------- resolve
+__global__ void __launch_bounds__(kBlock)
+resolve_kernel(PathBuffers pb, PassInfo ps, double* accum) {
+  uint32_t pixel = blockIdx.x * kBlock + threadIdx.x;
+  if (pixel >= ps.n_pixels) return;
+  double r, g, b;
+  uint32_t s = 0;
+  if (ps.first_pass) {  // Iterator::sum = reduce(a + b): starts from the first sample
+    double4 L = pb.radiance[pixel];
+    r = L.x;
+    g = L.y;
+    b = L.z;
+    s = 1;
+  } else {
+    r = accum[3 * (size_t)pixel + 0];
+    g = accum[3 * (size_t)pixel + 1];
+    b = accum[3 * (size_t)pixel + 2];
+  }
+  for (; s < ps.samples; ++s) {
+    double4 L = pb.radiance[(size_t)s * ps.n_pixels + pixel];
+    r = r + L.x;
+    g = g + L.y;
+    b = b + L.z;
+  }
+  accum[3 * (size_t)pixel + 0] = r;
+  accum[3 * (size_t)pixel + 1] = g;
+  accum[3 * (size_t)pixel + 2] = b;
+}
+
+__global__ void __launch_bounds__(kBlock)
+to_float_kernel(const double* in, float* out, uint64_t n) {
+  uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) out[i] = (float)in[i];
+}
+
+// ------------------------------------------------------------ first hit
+__global__ void __launch_bounds__(kBlock)
+first_hit_kernel(DeviceScene sc, PassInfo ps, uint32_t* id, double* t_out, double* normal) {
+  __shared__ uint32_t s_stack[kMaxBvhDepth * kBlock];
+  uint32_t local = blockIdx.x * kBlock + threadIdx.x;
+  if (local >= ps.n_pixels) return;
+  uint32_t x = ps.x0 + local % ps.ww, y = ps.y0 + local / ps.ww;
+  double u = ((double)x + 0.5) / ((double)ps.width - 1.0);
+  double v = ((double)(ps.height - y) + 0.5) / ((double)ps.height - 1.0);
+  const rt_camera& c = sc.cam;
+  V3 offset = v3(0.0, 0.0, 0.0);
+  V3 origin = vadd(v3(c.origin), offset);
+  V3 dir = vsub(vsub(vadd(vadd(v3(c.lower_left), vscale(v3(c.horizontal), u)),
+                          vscale(v3(c.vertical), v)),
+                     v3(c.origin)),
+                offset);
+  DrawKey key{0, 0, 0, 0};
+  Stats st;
+  Closest h = closest_hit<false, false>(sc, origin, dir, c.time0, 0.001, key,
+                                        s_stack + threadIdx.x, kBlock, st);
+  if (h.item == kNoPrim) {
+    id[local] = 0xFFFFFFFFu;
+    t_out[local] = 0.0;
+    normal[3 * (size_t)local + 0] = 0.0;
+    normal[3 * (size_t)local + 1] = 0.0;
+    normal[3 * (size_t)local + 2] = 0.0;
+    return;
+  }
+  const DPrim pr = sc.prims[h.item];
+  Record rec = make_record(sc, pr, origin, dir, c.time0, h.t, false);
+  id[local] = pr.object;
+  t_out[local] = h.t;
+  normal[3 * (size_t)local + 0] = rec.normal.x;
+  normal[3 * (size_t)local + 1] = rec.normal.y;
+  normal[3 * (size_t)local + 2] = rec.normal.z;
+}
+
+// ----------------------------------------------------------------- host
+
+template <typename T>
+struct DeviceArray {
+  T* p = nullptr;
+  size_t n = 0;
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+};
+
+}  // namespace
+
+struct rt_bvh {
+  FlatScene flat;
+};
+
+struct rt_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string error;
+  uint64_t max_paths = 0;
+  uint32_t n_cus = 0;
+  bool have_scene = false;
+  FlatScene flat;     // host copy (BVH inspection)
+  DeviceScene ds{};
+  DeviceArray<float4> nodes;
+  DeviceArray<DPrim> prims, boundary;
+  DeviceArray<uint32_t> ranks;
+  DeviceArray<DOp> ops;
+  DeviceArray<DAux> aux;
+  DeviceArray<DMaterial> materials;
+  DeviceArray<DTexture> textures;
+  DeviceArray<rt_perlin> perlin;
+  DeviceArray<DImage> images;
+  DeviceArray<uint8_t> texels;
+  // path buffers, grown on demand
+  PathBuffers pb{};
+  uint64_t pb_capacity = 0;
+  uint32_t counters_depth = 0;
+  DeviceArray<double> accum;
+  DeviceArray<unsigned long long> stats;
+  uint32_t* h_probe = nullptr;  // pinned word for queue-size probes
+};
+
+namespace {
+
+int fail(rt_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->error = msg;
+  return code;
+}
+
+#define RT_HIP(ctx, call)                                                                   \
+  do {                                                                                      \
+    hipError_t e__ = (call);                                                                \
+    if (e__ != hipSuccess)                                                                  \
+      return fail(ctx, e__ == hipErrorOutOfMemory ? RT_ERR_NOMEM : RT_ERR_DEVICE,           \
+                  std::string(#call) + ": " + hipGetErrorString(e__));                      \
+  } while (0)
+
+template <typename T, typename S>
+int upload(rt_ctx* ctx, DeviceArray<T>& dst, const std::vector<S>& src) {
+  static_assert(sizeof(T) % sizeof(S) == 0 || sizeof(S) % sizeof(T) == 0, "layout");
+  dst.release();
+  size_t bytes = src.size() * sizeof(S);
+  // keep every array non-null so kernels may form addresses even for empty scenes
+  RT_HIP(ctx, hipMalloc((void**)&dst.p, std::max<size_t>(bytes, 64)));
+  dst.n = bytes / sizeof(T);
+  if (bytes) RT_HIP(ctx, hipMemcpy(dst.p, src.data(), bytes, hipMemcpyHostToDevice));
+  return RT_OK;
+}
+
+void free_paths(rt_ctx* ctx) {
+  PathBuffers& pb = ctx->pb;
+  void* ptrs[] = {pb.ray_o, pb.ray_d, pb.beta, pb.radiance, pb.hit_item,
+                  pb.live[0], pb.live[1], pb.bins, pb.counters};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  pb = PathBuffers{};
+  ctx->pb_capacity = 0;
+  ctx->counters_depth = 0;
+}
+
+int ensure_paths(rt_ctx* ctx, uint64_t capacity, uint32_t max_depth) {
+  PathBuffers& pb = ctx->pb;
+  if (capacity > ctx->pb_capacity) {
+    uint32_t* keep_counters = pb.counters;
+    uint32_t keep_depth = ctx->counters_depth;
+    pb.counters = nullptr;
+    free_paths(ctx);
+    pb.counters = keep_counters;
+    ctx->counters_depth = keep_depth;
+    RT_HIP(ctx, hipMalloc((void**)&pb.ray_o, capacity * sizeof(double4)));
+    RT_HIP(ctx, hipMalloc((void**)&pb.ray_d, capacity * sizeof(double4)));
+    RT_HIP(ctx, hipMalloc((void**)&pb.beta, capacity * sizeof(double4)));
+    RT_HIP(ctx, hipMalloc((void**)&pb.radiance, capacity * sizeof(double4)));
+    RT_HIP(ctx, hipMalloc((void**)&pb.hit_item, capacity * sizeof(uint32_t)));
+    RT_HIP(ctx, hipMalloc((void**)&pb.live[0], capacity * sizeof(uint32_t)));
+    RT_HIP(ctx, hipMalloc((void**)&pb.live[1], capacity * sizeof(uint32_t)));
+    RT_HIP(ctx, hipMalloc((void**)&pb.bins, capacity * kBins * sizeof(uint32_t)));
+    pb.capacity = capacity;
+    ctx->pb_capacity = capacity;
+  }
+  if (max_depth > ctx->counters_depth) {
+    if (pb.counters) (void)hipFree(pb.counters);
+    pb.counters = nullptr;
+    RT_HIP(ctx, hipMalloc((void**)&pb.counters,
+                          (size_t)max_depth * kCounterStride * sizeof(uint32_t)));
+    ctx->counters_depth = max_depth;
+  }
+  return RT_OK;
+}
+
+int check_window(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_window* win, PassInfo& ps) {
+  if (width < 2 || height < 2) return fail(ctx, RT_ERR_INVALID, "image must be at least 2x2");
+  if ((uint64_t)width * height > 0xFFFFFFFFull)
+    return fail(ctx, RT_ERR_LIMIT, "image has more than 2^32-1 pixels");
+  ps.width = width;
+  ps.height = height;
+  if (!win || win->w == 0 || win->h == 0) {
+    ps.x0 = ps.y0 = 0;
+    ps.ww = width;
+    ps.wh = height;
+  } else {
+    if ((uint64_t)win->x0 + win->w > width || (uint64_t)win->y0 + win->h > height)
+      return fail(ctx, RT_ERR_INVALID, "window exceeds the image");
+    ps.x0 = win->x0;
+    ps.y0 = win->y0;
+    ps.ww = win->w;
+    ps.wh = win->h;
+  }
+  ps.n_pixels = ps.ww * ps.wh;
+  return RT_OK;
+}
+
+uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); }
+
+// Render the sample range into ctx->accum (f64 sums, window-sized).
+int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats) {
+  if (!ctx) return RT_ERR_INVALID;
+  if (!p) return fail(ctx, RT_ERR_INVALID, "null params");
+  if (!ctx->have_scene) return fail(ctx, RT_ERR_INVALID, "no scene uploaded");
+  if (p->sample_end < p->sample_begin) return fail(ctx, RT_ERR_INVALID, "empty sample range");
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  PassInfo ps{};
+  int rc = check_window(ctx, p->width, p->height, &p->window, ps);
+  if (rc != RT_OK) return rc;
+  ps.seed = p->seed;
+  const bool want_stats = (p->flags & RT_FLAG_STATS) && stats;
+  const uint32_t n_samples = p->sample_end - p->sample_begin;
+  const uint64_t n_pix = ps.n_pixels;
+  if (n_pix > ctx->max_paths)
+    return fail(ctx, RT_ERR_LIMIT, "window has more pixels than max_paths_in_flight");
+
+  if (ctx->accum.n < n_pix * 3) {
+    ctx->accum.release();
+    RT_HIP(ctx, hipMalloc((void**)&ctx->accum.p, n_pix * 3 * sizeof(double)));
+    ctx->accum.n = n_pix * 3;
+  }
+  RT_HIP(ctx, hipMemsetAsync(ctx->accum.p, 0, n_pix * 3 * sizeof(double), ctx->stream));
+  if (want_stats)
+    RT_HIP(ctx, hipMemsetAsync(ctx->stats.p, 0, RT_STAT_COUNT * sizeof(unsigned long long),
+                               ctx->stream));
+  if (n_samples == 0 || p->max_depth == 0) {
+    // depth 0: ray_color returns black for every sample (main.rs:121-122)
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (want_stats) std::memset(stats, 0, RT_STAT_COUNT * sizeof(uint64_t));
+    return RT_OK;
+  }
+
+  uint32_t per_pass = (uint32_t)std::min<uint64_t>(ctx->max_paths / n_pix, n_samples);
+  if (per_pass == 0) per_pass = 1;
+  rc = ensure_paths(ctx, n_pix * per_pass, p->max_depth);
+  if (rc != RT_OK) return rc;
+  const PathBuffers pb = ctx->pb;
+  const uint32_t max_grid = ctx->n_cus * 8u;
+  const bool media = ctx->flat.has_media;
+
+  for (uint32_t done = 0; done < n_samples; done += per_pass) {
+    ps.samples = std::min(per_pass, n_samples - done);
+    ps.sample_base = p->sample_begin + done;
+    ps.n_paths = (uint32_t)(n_pix * ps.samples);
+    ps.first_pass = done == 0 ? 1u : 0u;
+    RT_HIP(ctx, hipMemsetAsync(pb.counters, 0,
+                               (size_t)p->max_depth * kCounterStride * sizeof(uint32_t),
+                               ctx->stream));
+    raygen_kernel<<<blocks_for(ps.n_paths), kBlock, 0, ctx->stream>>>(ctx->ds, pb, ps);
+    uint32_t grid = std::min(blocks_for(ps.n_paths), max_grid);
+    for (uint32_t b = 0; b < p->max_depth; ++b) {
+      unsigned long long* gs = ctx->stats.p;
+      if (want_stats) {
+        if (media) extend_kernel<true, true><<<grid, kBlock, 0, ctx->stream>>>(ctx->ds, pb, ps, b, gs);
+        else extend_kernel<true, false><<<grid, kBlock, 0, ctx->stream>>>(ctx->ds, pb, ps, b, gs);
+        shade_kernel<true><<<grid, kBlock, 0, ctx->stream>>>(ctx->ds, pb, ps, b, p->max_depth, gs);
+      } else {
+        if (media) extend_kernel<false, true><<<grid, kBlock, 0, ctx->stream>>>(ctx->ds, pb, ps, b, gs);
+        else extend_kernel<false, false><<<grid, kBlock, 0, ctx->stream>>>(ctx->ds, pb, ps, b, gs);
+        shade_kernel<false><<<grid, kBlock, 0, ctx->stream>>>(ctx->ds, pb, ps, b, p->max_depth, gs);
+      }
+      // every 8 bounces look at the live count: stop when no path is left and
+      // shrink the grid as the queues drain
+      if ((b & 7u) == 7u && b + 1 < p->max_depth) {
+        RT_HIP(ctx, hipMemcpyAsync(ctx->h_probe, pb.counters + (size_t)b * kCounterStride + 6,
+                                   sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        uint32_t live = *ctx->h_probe;
+        if (live == 0) break;
+        grid = std::max(1u, std::min(blocks_for(live), max_grid));
+      }
+    }
+    resolve_kernel<<<blocks_for(n_pix), kBlock, 0, ctx->stream>>>(pb, ps, ctx->accum.p);
+  }
+  RT_HIP(ctx, hipGetLastError());
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (want_stats)
+    RT_HIP(ctx, hipMemcpy(stats, ctx->stats.p, RT_STAT_COUNT * sizeof(uint64_t),
+                          hipMemcpyDeviceToHost));
+  return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_create(const rt_config* cfg, rt_ctx** out) {
+  if (!out) return RT_ERR_INVALID;
+  *out = nullptr;
+  rt_ctx* ctx = new (std::nothrow) rt_ctx();
+  if (!ctx) return RT_ERR_NOMEM;
+  ctx->device = cfg ? cfg->device : 0;
+  ctx->max_paths = cfg && cfg->max_paths_in_flight ? cfg->max_paths_in_flight : (1ull << 25);
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0 || ctx->device < 0 || ctx->device >= count) {
+    delete ctx;
+    return RT_ERR_DEVICE;  // no usable HIP device: there is no other way to render
+  }
+  hipDeviceProp_t prop;
+  if (hipSetDevice(ctx->device) != hipSuccess ||
+      hipGetDeviceProperties(&prop, ctx->device) != hipSuccess ||
+      hipStreamCreate(&ctx->stream) != hipSuccess ||
+      hipMalloc((void**)&ctx->stats.p, RT_STAT_COUNT * sizeof(unsigned long long)) != hipSuccess ||
+      hipHostMalloc((void**)&ctx->h_probe, 64) != hipSuccess) {
+    delete ctx;
+    return RT_ERR_DEVICE;
+  }
+  ctx->n_cus = (uint32_t)prop.multiProcessorCount;
+  *out = ctx;
+  return RT_OK;
+}
+
+int rt_upload_scene(rt_ctx* ctx, const rt_scene* scene) {
+  if (!ctx) return RT_ERR_INVALID;
+  if (!scene) return fail(ctx, RT_ERR_INVALID, "null scene");
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  ctx->have_scene = false;
+  int code = RT_OK;
+  std::string err;
+  try {
+    err = flatten_scene(*scene, ctx->flat, code);
+  } catch (const std::exception& e) {
+    return fail(ctx, RT_ERR_NOMEM, e.what());
+  }
+  if (!err.empty()) return fail(ctx, code, err);
+  const FlatScene& f = ctx->flat;
+  int rc;
+  if ((rc = upload(ctx, ctx->nodes, f.nodes)) != RT_OK) return rc;
+  if ((rc = upload(ctx, ctx->prims, f.prims)) != RT_OK) return rc;
+  if ((rc = upload(ctx, ctx->ranks, f.ranks)) != RT_OK) return rc;
+  if ((rc = upload(ctx, ctx->boundary, f.boundary)) != RT_OK) return rc;
+  if ((rc = upload(ctx, ctx->ops, f.ops)) != RT_OK) return rc;
+  if ((rc = upload(ctx, ctx->aux, f.aux)) != RT_OK) return rc;
+  if ((rc = upload(ctx, ctx->materials, f.materials)) != RT_OK) return rc;
+  if ((rc = upload(ctx, ctx->textures, f.textures)) != RT_OK) return rc;
+  if ((rc = upload(ctx, ctx->perlin, f.perlin)) != RT_OK) return rc;
+  if ((rc = upload(ctx, ctx->images, f.images)) != RT_OK) return rc;
+  if ((rc = upload(ctx, ctx->texels, f.texels)) != RT_OK) return rc;
+  DeviceScene& ds = ctx->ds;
+  ds.nodes = ctx->nodes.p;
+  ds.prims = ctx->prims.p;
+  ds.ranks = ctx->ranks.p;
+  ds.boundary = ctx->boundary.p;
+  ds.ops = ctx->ops.p;
+  ds.aux = ctx->aux.p;
+  ds.materials = ctx->materials.p;
+  ds.textures = ctx->textures.p;
+  ds.perlin = ctx->perlin.p;
+  ds.images = ctx->images.p;
+  ds.texels = ctx->texels.p;
+  ds.n_nodes = (uint32_t)f.nodes.size();
+  ds.has_media = f.has_media ? 1u : 0u;
+  ds.cam = f.camera;
+  std::memcpy(ds.bg, f.background, sizeof ds.bg);
+  ctx->have_scene = true;
+  return RT_OK;
+}
+
+int rt_render_f64(rt_ctx* ctx, const rt_render_params* p, double* rgb_sum, uint64_t* stats) {
+  if (!ctx) return RT_ERR_INVALID;
+  if (!rgb_sum) return fail(ctx, RT_ERR_INVALID, "null output");
+  int rc = render_into_accum(ctx, p, stats);
+  if (rc != RT_OK) return rc;
+  PassInfo ps{};
+  check_window(ctx, p->width, p->height, &p->window, ps);
+  RT_HIP(ctx, hipMemcpy(rgb_sum, ctx->accum.p, (size_t)ps.n_pixels * 3 * sizeof(double),
+                        hipMemcpyDeviceToHost));
+  return RT_OK;
+}
+
+int rt_render_device(rt_ctx* ctx, const rt_render_params* p, float* d_rgb_sum, uint64_t* stats) {
+  if (!ctx) return RT_ERR_INVALID;
+  if (!d_rgb_sum) return fail(ctx, RT_ERR_INVALID, "null output");
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, d_rgb_sum) != hipSuccess ||
+      attr.type != hipMemoryTypeDevice || attr.device != ctx->device) {
+    (void)hipGetLastError();
+    return fail(ctx, RT_ERR_INVALID, "output is not device memory of the context's device");
+  }
+  int rc = render_into_accum(ctx, p, stats);
+  if (rc != RT_OK) return rc;
+  PassInfo ps{};
+  check_window(ctx, p->width, p->height, &p->window, ps);
+  uint64_t n = (uint64_t)ps.n_pixels * 3;
+  to_float_kernel<<<blocks_for(n), kBlock, 0, ctx->stream>>>(ctx->accum.p, d_rgb_sum, n);
+  RT_HIP(ctx, hipGetLastError());
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return RT_OK;
+}
+
+int rt_render(rt_ctx* ctx, const rt_render_params* p, float* rgb_sum, uint64_t* stats) {
+  if (!ctx) return RT_ERR_INVALID;
+  if (!rgb_sum) return fail(ctx, RT_ERR_INVALID, "null output");
+  int rc = render_into_accum(ctx, p, stats);
+  if (rc != RT_OK) return rc;
+  PassInfo ps{};
+  check_window(ctx, p->width, p->height, &p->window, ps);
+  uint64_t n = (uint64_t)ps.n_pixels * 3;
+  float* d_out = nullptr;
+  RT_HIP(ctx, hipMalloc((void**)&d_out, n * sizeof(float)));
+  to_float_kernel<<<blocks_for(n), kBlock, 0, ctx->stream>>>(ctx->accum.p, d_out, n);
+  hipError_t e = hipMemcpyAsync(rgb_sum, d_out, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d_out);
+  if (e != hipSuccess) return fail(ctx, RT_ERR_DEVICE, hipGetErrorString(e));
+  return RT_OK;
+}
+
+int rt_first_hit(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_window* window,
+                 uint32_t* id, double* t, double* normal) {
+  if (!ctx) return RT_ERR_INVALID;
+  if (!id || !t || !normal) return fail(ctx, RT_ERR_INVALID, "null output");
+  if (!ctx->have_scene) return fail(ctx, RT_ERR_INVALID, "no scene uploaded");
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  PassInfo ps{};
+  int rc = check_window(ctx, width, height, window, ps);
+  if (rc != RT_OK) return rc;
+  size_t n = ps.n_pixels;
+  uint32_t* d_id = nullptr;
+  double *d_t = nullptr, *d_n = nullptr;
+  hipError_t e = hipMalloc((void**)&d_id, n * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&d_t, n * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&d_n, n * 3 * sizeof(double));
+  if (e == hipSuccess) {
+    first_hit_kernel<<<blocks_for(n), kBlock, 0, ctx->stream>>>(ctx->ds, ps, d_id, d_t, d_n);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) e = hipMemcpy(id, d_id, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(t, d_t, n * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(normal, d_n, n * 3 * sizeof(double), hipMemcpyDeviceToHost);
+  if (d_id) (void)hipFree(d_id);
+  if (d_t) (void)hipFree(d_t);
+  if (d_n) (void)hipFree(d_n);
+  if (e != hipSuccess)
+    return fail(ctx, e == hipErrorOutOfMemory ? RT_ERR_NOMEM : RT_ERR_DEVICE, hipGetErrorString(e));
+  return RT_OK;
+}
+
+int rt_bvh_build(const rt_scene* scene, rt_bvh** out) {
+  if (!scene || !out) return RT_ERR_INVALID;
+  *out = nullptr;
+  rt_bvh* b = new (std::nothrow) rt_bvh();
+  if (!b) return RT_ERR_NOMEM;
+  int code = RT_OK;
+  std::string err;
+  try {
+    err = flatten_scene(*scene, b->flat, code);
+  } catch (const std::exception&) {
+    delete b;
+    return RT_ERR_NOMEM;
+  }
+  if (!err.empty()) {
+    delete b;
+    return code;
+  }
+  *out = b;
+  return RT_OK;
+}
+
+int rt_bvh_info(const rt_bvh* bvh, uint32_t* n_nodes, uint32_t* n_items, uint32_t* max_depth) {
+  if (!bvh) return RT_ERR_INVALID;
+  if (n_nodes) *n_nodes = (uint32_t)bvh->flat.nodes.size();
+  if (n_items) *n_items = (uint32_t)bvh->flat.items.size();
+  if (max_depth) *max_depth = bvh->flat.bvh_depth;
+  return RT_OK;
+}
+
+int rt_bvh_copy(const rt_bvh* bvh, rt_bvh_node* nodes, rt_bvh_item* items) {
+  if (!bvh || !nodes || !items) return RT_ERR_INVALID;
+  if (!bvh->flat.nodes.empty())
+    std::memcpy(nodes, bvh->flat.nodes.data(), bvh->flat.nodes.size() * sizeof(rt_bvh_node));
+  if (!bvh->flat.items.empty())
+    std::memcpy(items, bvh->flat.items.data(), bvh->flat.items.size() * sizeof(rt_bvh_item));
+  return RT_OK;
+}
+
+void rt_bvh_free(rt_bvh* bvh) { delete bvh; }
+
+const char* rt_last_error(const rt_ctx* ctx) { return ctx ? ctx->error.c_str() : "null context"; }
+
+void rt_destroy(rt_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  free_paths(ctx);
+  ctx->nodes.release();
+  ctx->prims.release();
+  ctx->boundary.release();
+  ctx->ranks.release();
+  ctx->ops.release();
+  ctx->aux.release();
+  ctx->materials.release();
+  ctx->textures.release();
+  ctx->perlin.release();
+  ctx->images.release();
+  ctx->texels.release();
+  ctx->accum.release();
+  ctx->stats.release();
+  if (ctx->h_probe) (void)hipHostFree(ctx->h_probe);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+}  // extern "C"

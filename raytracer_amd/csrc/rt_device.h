@@ -1,0 +1,520 @@
+// Device-side geometry, traversal, materials and textures.
+//
+// Arithmetic that decides WHAT the reference would compute (primitive tests,
+// hit records, scattering, textures) is written operation for operation in f64
+// after the cited reference lines and compiled without FMA contraction; the
+// box culling in front of it is free to use FMA because it only has to be
+// conservative.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_scene.h"
+#include "philox.h"
+
+namespace rt {
+
+#define RT_DEV __device__ __forceinline__
+
+struct DeviceScene {
+  const float4* nodes;   // 2 x float4 per node
+  const DPrim* prims;
+  const uint32_t* ranks;
+  const DPrim* boundary;
+  const DOp* ops;
+  const DAux* aux;
+  const DMaterial* materials;
+  const DTexture* textures;
+  const rt_perlin* perlin;
+  const DImage* images;
+  const uint8_t* texels;
+  uint32_t n_nodes;
+  uint32_t has_media;
+  rt_camera cam;
+  double bg[3];
+};
+
+// ------------------------------------------------------------------- Vec3
+// Operators spelled as src/geom/vec3.rs:141-225 spells them.
+struct V3 {
+  double x, y, z;
+};
+RT_DEV V3 v3(double x, double y, double z) { return V3{x, y, z}; }
+RT_DEV V3 v3(const double* p) { return V3{p[0], p[1], p[2]}; }
+RT_DEV V3 vneg(V3 a) { return V3{-a.x, -a.y, -a.z}; }
+RT_DEV V3 vadd(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+RT_DEV V3 vsub(V3 a, V3 b) { return vadd(a, vneg(b)); }  // a + (-b)
+RT_DEV V3 vscale(V3 a, double s) { return V3{a.x * s, a.y * s, a.z * s}; }
+RT_DEV V3 vmul(V3 a, V3 b) { return V3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+RT_DEV V3 vdiv(V3 a, double s) { return vscale(a, 1.0 / s); }  // a * s.recip()
+RT_DEV double vdot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RT_DEV double vlen2(V3 a) { return vdot(a, a); }
+RT_DEV double vlen(V3 a) { return sqrt(vlen2(a)); }
+RT_DEV V3 vunit(V3 a) { return vdiv(a, vlen(a)); }
+RT_DEV V3 vreflect(V3 v, V3 n) { return vsub(v, vscale(n, 2.0 * vdot(v, n))); }  // vec3.rs:83-85
+RT_DEV V3 vrefract(V3 v, V3 n, double eta) {                                      // vec3.rs:87-92
+  double cos_theta = fmin(vdot(vneg(v), n), 1.0);
+  V3 perp = vscale(vadd(v, vscale(n, cos_theta)), eta);
+  V3 par = vscale(vneg(n), sqrt(fabs(1.0 - vlen2(perp))));
+  return vadd(perp, par);
+}
+RT_DEV bool vnear_zero(V3 v) {  // vec3.rs:118-121
+  const double LIMIT = 0.001;
+  return fabs(v.x) < LIMIT && fabs(v.y) < LIMIT && fabs(v.z) < LIMIT;
+}
+RT_DEV double vget(V3 v, uint32_t axis) { return axis == 0 ? v.x : (axis == 1 ? v.y : v.z); }
+RT_DEV double powi5(double x) {  // powi(5) as compiler-rt expands it: x * (x^2)^2
+  double x2 = x * x;
+  double x4 = x2 * x2;
+  return x * x4;
+}
+
+// ---------------------------------------------------------------- drawing
+struct DrawKey {
+  uint64_t seed;
+  uint32_t pixel, sample, bounce;
+};
+RT_DEV u32x4 draw(const DrawKey& k, uint32_t purpose, uint32_t seq) {
+  return draw_block(k.seed, k.pixel, k.sample, k.bounce, purpose, seq);
+}
+const uint32_t kMaxRejections = 4096;  // the loop ends with probability 1 - 2^-4000 long before
+
+RT_DEV V3 rand_unit_vector(const DrawKey& k) {  // vec3.rs:35-47
+  V3 v = v3(0.0, 0.0, 0.0);
+  for (uint32_t it = 0; it < kMaxRejections; ++it) {
+    sym3_42(draw(k, DRAW_SCATTER, it), v.x, v.y, v.z);
+    if (vlen2(v) < 1.0) break;
+  }
+  return vunit(v);
+}
+RT_DEV V3 rand_in_unit_disk(const DrawKey& k) {  // vec3.rs:49-60
+  V3 v = v3(0.0, 0.0, 0.0);
+  for (uint32_t it = 0; it < kMaxRejections; ++it) {
+    double unused;
+    sym3_42(draw(k, DRAW_LENS, it), v.x, v.y, unused);
+    v.z = 0.0;
+    if (vlen2(v) < 1.0) break;
+  }
+  return v;
+}
+
+// ------------------------------------------------------------- statistics
+struct Stats {
+  uint32_t v[RT_STAT_COUNT];
+  RT_DEV void clear() {
+#pragma unroll
+    for (int i = 0; i < RT_STAT_COUNT; ++i) v[i] = 0;
+  }
+};
+template <bool ON>
+RT_DEV void stat(Stats& s, int which) {
+  if (ON) s.v[which]++;
+}
+
+// ---------------------------------------------------------------- records
+RT_DEV uint32_t ops_first(uint32_t w) { return w & 0x00FFFFFFu; }
+RT_DEV uint32_t ops_count(uint32_t w) { return w >> 24; }
+
+// Forward (world -> innermost frame) transform of a ray through wrapper ops,
+// outermost first: Translate::hit instance.rs:13, RotateY::hit instance.rs:52-61.
+template <bool STATS>
+RT_DEV void ops_forward(const DeviceScene& sc, uint32_t ops_word, uint32_t upto, V3& o, V3& d,
+                        Stats& st) {
+  const DOp* ops = sc.ops + ops_first(ops_word);
+  for (uint32_t k = 0; k < upto; ++k) {
+    const DOp op = ops[k];
+    if (op.kind == RT_OP_TRANSLATE) {
+      stat<STATS>(st, RT_STAT_OP_TRANSLATE);
+      o = vsub(o, v3(op.a));
+    } else {
+      stat<STATS>(st, RT_STAT_OP_ROTATE);
+      double s = op.a[0], c = op.a[1];
+      V3 no = o, nd = d;
+      no.x = c * o.x - s * o.z;
+      no.z = s * o.x + c * o.z;
+      nd.x = c * d.x - s * d.z;
+      nd.z = s * d.x + c * d.z;
+      o = no;
+      d = nd;
+    }
+  }
+}
+
+// Direction of the ray as seen by wrapper `level` (after ops [0, level]).
+RT_DEV V3 ops_direction(const DeviceScene& sc, uint32_t ops_word, uint32_t level, V3 d) {
+  const DOp* ops = sc.ops + ops_first(ops_word);
+  for (uint32_t k = 0; k <= level; ++k) {
+    if (ops[k].kind == RT_OP_ROTATE_Y) {
+      double s = ops[k].a[0], c = ops[k].a[1];
+      V3 nd = d;
+      nd.x = c * d.x - s * d.z;
+      nd.z = s * d.x + c * d.z;
+      d = nd;
+    }
+  }
+  return d;
+}
+
+struct Record {  // HitRecord, src/hittable/mod.rs:32-40 (material and t live elsewhere)
+  V3 p, normal;
+  double u, v;
+  bool front;
+};
+
+RT_DEV void set_face_normal(Record& r, V3 dir, V3 outward) {  // mod.rs:65-68
+  r.front = vdot(dir, outward) < 0.0;
+  r.normal = r.front ? outward : vneg(outward);
+}
+
+// Backward pass of the wrappers over a record, innermost first
+// (Translate instance.rs:14-18, RotateY instance.rs:63-82 with its x-for-z slip kept).
+RT_DEV void ops_backward(const DeviceScene& sc, uint32_t ops_word, V3 world_dir, Record& r) {
+  const DOp* ops = sc.ops + ops_first(ops_word);
+  for (uint32_t k = ops_count(ops_word); k-- > 0;) {
+    const DOp op = ops[k];
+    V3 dir = ops_direction(sc, ops_word, k, world_dir);
+    if (op.kind == RT_OP_TRANSLATE) {
+      r.p = vadd(r.p, v3(op.a));
+      set_face_normal(r, dir, r.normal);
+    } else {
+      double s = op.a[0], c = op.a[1];
+      V3 p = r.p, n = r.normal;
+      p.x = c * r.p.x + s * r.p.x;
+      p.z = -s * r.p.x + c * r.p.x;
+      n.x = c * r.normal.x + s * r.normal.x;
+      n.z = -s * r.normal.x + c * r.normal.x;
+      r.p = p;
+      set_face_normal(r, dir, n);
+    }
+  }
+}
+
+RT_DEV V3 moving_center(const DeviceScene& sc, const DPrim& pr, double time) {  // moving_sphere.rs:20-23
+  const DAux ax = sc.aux[(uint32_t)pr.p[5]];
+  double t0 = pr.p[4], t1 = ax.v[3];
+  double portion = (t0 - time) / (t1 - t0);
+  V3 c0 = v3(pr.p[0], pr.p[1], pr.p[2]), c1 = v3(ax.v[0], ax.v[1], ax.v[2]);
+  return vadd(vscale(c0, 1.0 - portion), vscale(c1, portion));  // lerp, interpolate.rs:3-9
+}
+
+RT_DEV bool in_range(double t, double lo, double hi) { return lo <= t && t < hi; }  // Range::contains
+
+// Sphere::hit up to the root (sphere.rs:32-51).
+RT_DEV bool sphere_t(V3 c, double radius, V3 o, V3 d, double tmin, double tmax, double& t) {
+  V3 oc = vsub(o, c);
+  double a = vlen2(d);
+  double half_b = vdot(oc, d);
+  double cc = vlen2(oc) - radius * radius;
+  double discrim = half_b * half_b - a * cc;
+  if (discrim < 0.0) return false;
+  double sqrtd = sqrt(discrim);
+  double root = (-half_b - sqrtd) / a;
+  if (!in_range(root, tmin, tmax)) {
+    root = (-half_b + sqrtd) / a;
+    if (!in_range(root, tmin, tmax)) return false;
+  }
+  t = root;
+  return true;
+}
+
+// AxisAlignedRect::hit up to the containment test (rect.rs:39-51).
+RT_DEV bool rect_t(const DPrim& pr, V3 o, V3 d, double tmin, double tmax, double& t) {
+  uint32_t d0 = (pr.kind >> 4) & 3u;
+  uint32_t d1 = d0 == 2 ? 0 : d0 + 1;
+  uint32_t d2 = d1 == 2 ? 0 : d1 + 1;
+  double tt = (pr.p[0] - vget(o, d0)) / vget(d, d0);
+  if (!in_range(tt, tmin, tmax)) return false;
+  double i = vget(o, d1) + tt * vget(d, d1);
+  double j = vget(o, d2) + tt * vget(d, d2);
+  if (!(pr.p[1] <= i && i <= pr.p[2]) || !(pr.p[3] <= j && j <= pr.p[4])) return false;
+  t = tt;
+  return true;
+}
+
+// hit().t of one base primitive inside its wrappers, for a ray given in the frame
+// outside those wrappers.
+template <bool STATS>
+RT_DEV bool base_prim_t(const DeviceScene& sc, const DPrim& pr, V3 o, V3 d, double time,
+                        double tmin, double tmax, double& t, Stats& st) {
+  uint32_t n_ops = ops_count(pr.ops);
+  if (n_ops) ops_forward<STATS>(sc, pr.ops, n_ops, o, d, st);
+  uint32_t kind = pr.kind & 15u;
+  if (kind == DP_SPHERE) {
+    stat<STATS>(st, RT_STAT_SPHERE_TESTS);
+    return sphere_t(v3(pr.p[0], pr.p[1], pr.p[2]), pr.p[3], o, d, tmin, tmax, t);
+  }
+  if (kind == DP_MOVING_SPHERE) {
+    stat<STATS>(st, RT_STAT_MSPHERE_TESTS);
+    return sphere_t(moving_center(sc, pr, time), pr.p[3], o, d, tmin, tmax, t);
+  }
+  stat<STATS>(st, RT_STAT_RECT_TESTS);
+  return rect_t(pr, o, d, tmin, tmax, t);
+}
+
+// boundary.hit(ray, range).t for a medium: first minimum over its primitives
+// (HittableList::hit, hittable_list.rs:28-31).
+template <bool STATS>
+RT_DEV bool boundary_t(const DeviceScene& sc, uint32_t first, uint32_t count, V3 o, V3 d,
+                       double time, double tmin, double tmax, double& t, Stats& st) {
+  bool any = false;
+  for (uint32_t k = 0; k < count; ++k) {
+    const DPrim pr = sc.boundary[first + k];
+    double tk;
+    if (base_prim_t<STATS>(sc, pr, o, d, time, tmin, tmax, tk, st)) {
+      if (!any || tk < t) t = tk;
+      any = true;
+    }
+  }
+  return any;
+}
+
+// ConstantMedium::hit (constant_medium.rs:27-76) up to t.
+template <bool STATS>
+RT_DEV bool medium_t(const DeviceScene& sc, const DPrim& pr, V3 o, V3 d, double time, double tmin,
+                     double tmax, const DrawKey& key, double& t, Stats& st) {
+  stat<STATS>(st, RT_STAT_MEDIUM_TESTS);
+  uint32_t n_ops = ops_count(pr.ops);
+  if (n_ops) ops_forward<STATS>(sc, pr.ops, n_ops, o, d, st);
+  const double inf = __longlong_as_double(0x7FF0000000000000ll);
+  uint32_t first = (uint32_t)pr.p[1], count = (uint32_t)pr.p[2];
+  double t1, t2;
+  if (!boundary_t<STATS>(sc, first, count, o, d, time, -inf, inf, t1, st)) return false;
+  if (!boundary_t<STATS>(sc, first, count, o, d, time, t1 + 0.0001, inf, t2, st)) return false;
+  if (t1 < tmin) t1 = tmin;
+  if (t2 > tmax) t2 = tmax;
+  if (t1 >= t2) return false;
+  if (t1 < 0.0) t1 = 0.0;
+  double ray_length = vlen(d);
+  double distance_inside = (t2 - t1) * ray_length;
+  u32x4 b = draw(key, DRAW_MEDIUM, pr.object);
+  double hit_distance = pr.p[0] * log10(u01_53(b.x, b.y));
+  if (hit_distance > distance_inside) return false;
+  t = t1 + hit_distance / ray_length;
+  return true;
+}
+
+RT_DEV void sphere_uv(V3 n, double& u, double& v) {  // Sphere::get_uv, sphere.rs:20-24
+  const double PI = 3.14159265358979323846264338327950288;
+  double theta = acos(-n.y);
+  double phi = atan2(-n.z, n.x) + PI;
+  u = phi / (2.0 * PI);
+  v = theta / PI;
+}
+
+// The HitRecord the reference would return for leaf slot `pr` hit at parameter t
+// by the world-frame ray (o, d, time).
+RT_DEV Record make_record(const DeviceScene& sc, const DPrim& pr, V3 o, V3 d, double time, double t,
+                          bool want_uv) {
+  Record r;
+  r.u = 0.0;
+  r.v = 0.0;
+  Stats unused;
+  uint32_t kind = pr.kind & 15u;
+  uint32_t n_ops = ops_count(pr.ops);
+  V3 lo = o, ld = d;
+  if (n_ops) ops_forward<false>(sc, pr.ops, n_ops, lo, ld, unused);
+  if (kind == DP_MEDIUM) {  // constant_medium.rs:63-75
+    r.p = vadd(lo, vscale(ld, t));
+    set_face_normal(r, ld, v3(1.0, 0.0, 0.0));
+  } else if (kind == DP_RECT) {  // rect.rs:53-64
+    uint32_t d0 = (pr.kind >> 4) & 3u;
+    r.p = vadd(lo, vscale(ld, t));
+    if (want_uv) {
+      uint32_t d1 = d0 == 2 ? 0 : d0 + 1;
+      uint32_t d2 = d1 == 2 ? 0 : d1 + 1;
+      double i = vget(lo, d1) + t * vget(ld, d1);
+      double j = vget(lo, d2) + t * vget(ld, d2);
+      r.u = (i - pr.p[1]) / (pr.p[2] + -pr.p[1]);
+      r.v = (j - pr.p[3]) / (pr.p[4] + -pr.p[3]);
+    }
+    V3 outward = v3(d0 == 0 ? 1.0 : 0.0, d0 == 1 ? 1.0 : 0.0, d0 == 2 ? 1.0 : 0.0);
+    set_face_normal(r, ld, outward);
+  } else {  // sphere.rs:52-63
+    V3 c = kind == DP_SPHERE ? v3(pr.p[0], pr.p[1], pr.p[2]) : moving_center(sc, pr, time);
+    r.p = vadd(lo, vscale(ld, t));
+    V3 outward = vdiv(vsub(r.p, c), pr.p[3]);
+    if (want_uv) sphere_uv(outward, r.u, r.v);
+    set_face_normal(r, ld, outward);
+  }
+  if (n_ops) ops_backward(sc, pr.ops, d, r);
+  return r;
+}
+
+// -------------------------------------------------------------- traversal
+// 1/d for the slab test.  A zero (or denormal) component would give an infinite
+// reciprocal and inf - inf = NaN in `lo * inv - o * inv`; a huge finite value
+// keeps every product finite and still puts the slab planes beyond any real t.
+RT_DEV double cull_reciprocal(double d) {
+  const double big = 1e150;
+  double inv = 1.0 / d;
+  return fabs(inv) <= big ? inv : copysign(big, d);
+}
+
+struct Closest {
+  double t;
+  uint32_t item;  // leaf slot, or kNoPrim
+};
+
+// world.hit(ray, tmin..inf): closest t over the flattened BVH.  Each visited node
+// is slab-tested against [tmin, best t]; an interior node pushes its far child
+// (by direction sign on the split axis) and continues with the near one.  Equal
+// t resolves to the lower rank.  `stack` is this lane's column of the LDS stack,
+// entries `stride` words apart.
+template <bool STATS, bool MEDIA>
+RT_DEV Closest closest_hit(const DeviceScene& sc, V3 o, V3 d, double time, double tmin,
+                           const DrawKey& key, uint32_t* stack, uint32_t stride, Stats& st) {
+  const double inf = __longlong_as_double(0x7FF0000000000000ll);
+  Closest best;
+  best.t = inf;
+  best.item = kNoPrim;
+  if (sc.n_nodes == 0) return best;
+  // culling arithmetic: 1/d and -o/d once per ray, one FMA per slab plane
+  double ix = cull_reciprocal(d.x), iy = cull_reciprocal(d.y), iz = cull_reciprocal(d.z);
+  double nx = -(o.x * ix), ny = -(o.y * iy), nz = -(o.z * iz);
+  uint32_t sp = 0;
+  uint32_t node = 0;
+  const uint32_t kNone = 0xFFFFFFFFu;
+  while (node != kNone) {
+    // walk down until a leaf passes its box test
+    uint32_t leaf_first = 0, leaf_count = 0;
+    while (node != kNone) {
+      float4 n0 = sc.nodes[2 * node];
+      float4 n1 = sc.nodes[2 * node + 1];
+      stat<STATS>(st, RT_STAT_BOX_TESTS);
+      double ax = __builtin_fma((double)n0.x, ix, nx), bx = __builtin_fma((double)n0.w, ix, nx);
+      double ay = __builtin_fma((double)n0.y, iy, ny), by = __builtin_fma((double)n1.x, iy, ny);
+      double az = __builtin_fma((double)n0.z, iz, nz), bz = __builtin_fma((double)n1.y, iz, nz);
+      double t0 = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmax(fmin(az, bz), tmin));
+      double t1 = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmin(fmax(az, bz), best.t));
+      uint32_t a = __float_as_uint(n1.z), b = __float_as_uint(n1.w);
+      if (t0 <= t1) {
+        if (b & 0x80000000u) {
+          uint32_t axis = b & 3u;
+          uint32_t neg = vget(d, axis) < 0.0 ? 1u : 0u;
+          stack[sp * stride] = a + 1u - neg;
+          ++sp;
+          node = a + neg;
+          continue;
+        }
+        leaf_first = a;
+        leaf_count = b;
+        node = sp ? stack[(--sp) * stride] : kNone;
+        break;
+      }
+      node = sp ? stack[(--sp) * stride] : kNone;
+    }
+    for (uint32_t k = 0; k < leaf_count; ++k) {
+      uint32_t slot = leaf_first + k;
+      const DPrim pr = sc.prims[slot];
+      double t;
+      bool hit;
+      if (MEDIA && (pr.kind & 15u) == DP_MEDIUM)
+        hit = medium_t<STATS>(sc, pr, o, d, time, tmin, inf, key, t, st);
+      else if (!MEDIA && (pr.kind & 15u) == DP_MEDIUM)
+        hit = false;
+      else
+        hit = base_prim_t<STATS>(sc, pr, o, d, time, tmin, inf, t, st);
+      if (hit) {
+        if (t < best.t || (t == best.t && best.item != kNoPrim &&
+                           sc.ranks[slot] < sc.ranks[best.item])) {
+          best.t = t;
+          best.item = slot;
+        }
+      }
+    }
+  }
+  return best;
+}
+
+// ---------------------------------------------------------------- textures
+RT_DEV double perlin_noise(const rt_perlin* t, V3 p) {  // perlin.rs:38-63 and :79-100
+  double fx = floor(p.x), fy = floor(p.y), fz = floor(p.z);
+  double u = p.x - fx, v = p.y - fy, w = p.z - fz;
+  u = u * u * (3.0 - 2.0 * u);
+  v = v * v * (3.0 - 2.0 * v);
+  w = w * w * (3.0 - 2.0 * w);
+  long long i = (long long)fx, j = (long long)fy, k = (long long)fz;
+  double uu = u * u * (3.0 - 2.0 * u);
+  double vv = v * v * (3.0 - 2.0 * v);
+  double ww = w * w * (3.0 - 2.0 * w);
+  double accum = 0.0;
+#pragma unroll
+  for (int di = 0; di < 2; ++di)
+#pragma unroll
+    for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+      for (int dk = 0; dk < 2; ++dk) {
+        uint32_t idx = t->perm_x[(i + di) & 0xFF] ^ t->perm_y[(j + dj) & 0xFF] ^
+                       t->perm_z[(k + dk) & 0xFF];
+        V3 c = v3(t->rand_vec[idx][0], t->rand_vec[idx][1], t->rand_vec[idx][2]);
+        double fi = (double)di, fj = (double)dj, fk = (double)dk;
+        V3 weight_v = v3(u - fi, v - fj, w - fk);
+        accum += vdot(c, weight_v) * (fi * uu + (1.0 - fi) * (1.0 - uu)) *
+                 (fj * vv + (1.0 - fj) * (1.0 - vv)) * (fk * ww + (1.0 - fk) * (1.0 - ww));
+      }
+  return accum;
+}
+
+RT_DEV double perlin_turb(const rt_perlin* t, V3 p, int depth) {  // perlin.rs:65-76
+  double accum = 0.0, weight = 1.0;
+  for (int i = 0; i < depth; ++i) {
+    accum += weight * perlin_noise(t, p);
+    weight *= 0.5;
+    p = vscale(p, 2.0);
+  }
+  return fabs(accum);
+}
+
+// Rust `as u32` from f64: saturating, NaN -> 0.
+RT_DEV uint32_t as_u32_sat(double x) {
+  if (!(x == x)) return 0u;
+  if (x <= 0.0) return 0u;
+  if (x >= 4294967295.0) return 4294967295u;
+  return (uint32_t)x;
+}
+
+template <bool STATS>
+RT_DEV V3 texture_value(const DeviceScene& sc, uint32_t tex, double u, double v, V3 p, Stats& st) {
+  DTexture t = sc.textures[tex];
+  // Checkerboard::value (checkerboard.rs:17-28); children have lower indices, so this ends
+  while (t.kind == RT_TEX_CHECKER) {
+    stat<STATS>(st, RT_STAT_TEX_CHECKER);
+    double sines = 1.0;
+    sines = sines * sin(p.x * 10.0);
+    sines = sines * sin(p.y * 10.0);
+    sines = sines * sin(p.z * 10.0);
+    t = sc.textures[sines < 0.0 ? t.b : t.a];
+  }
+  if (t.kind == RT_TEX_SOLID) return v3(t.color);
+  if (t.kind == RT_TEX_PERLIN) {  // perlin.rs:109-116
+    stat<STATS>(st, RT_STAT_TEX_PERLIN);
+    // Color::white() * 0.5 * (1 + sin(..)): per channel (1.0 * 0.5) * (..)
+    double half = 1.0 * 0.5;
+    double val = half * (1.0 + sin(t.scale * p.z + 10.0 * perlin_turb(sc.perlin + t.a, p, 7)));
+    return v3(val, val, val);
+  }
+  // Image::value (image.rs:24-35)
+  stat<STATS>(st, RT_STAT_TEX_IMAGE);
+  const DImage im = sc.images[t.a];
+  uint32_t w = im.width, h = im.height;
+  uint32_t i = min(as_u32_sat(u * (double)w), w - 1u);
+  uint32_t j = min(h - as_u32_sat(v * (double)h), h - 1u);  // u32 wrap, then clamp, as in release Rust
+  const uint8_t* px = sc.texels + im.offset + ((size_t)j * w + i) * 3u;
+  double scale = 1.0 / 255.0;  // vec3.rs:289-297
+  return v3((double)px[0] * scale, (double)px[1] * scale, (double)px[2] * scale);
+}
+
+// --------------------------------------------------------------- materials
+struct Scatter {
+  V3 attenuation;
+  V3 direction;
+  bool scattered;
+};
+
+RT_DEV double reflectance(double cosine, double ref_idx) {  // dielectric.rs:42-46
+  double q = (1.0 - ref_idx) / (1.0 + ref_idx);
+  double r0 = q * q;
+  return r0 + (1.0 - r0) * powi5(1.0 - cosine);
+}
+
+}  // namespace rt
