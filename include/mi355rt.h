@@ -244,7 +244,9 @@ typedef struct rt_window { /* sub-rectangle of the image; w==0 means the whole i
   uint32_t x0, y0, w, h;
 } rt_window;
 
-#define RT_FLAG_STATS 1u       /* fill the stats array (instrumented kernels) */
+#define RT_FLAG_STATS 1u       /* fill the operation counts of the stats array (instrumented kernels) */
+#define RT_FLAG_TIMING 2u      /* fill the RT_STAT_*_NS / *_LAUNCHES slots: device time of the extend
+                                  and shade kernels, from events recorded around every launch */
 
 typedef struct rt_render_params {
   uint32_t width, height;      /* full image size: sets u,v (src/main.rs:91-93) and RNG pixel index */
@@ -275,6 +277,11 @@ enum {
   RT_STAT_TEX_CHECKER,
   RT_STAT_TEX_PERLIN,
   RT_STAT_TEX_IMAGE,
+  RT_STAT_SPHERE_ROOTS,    /* sphere tests whose discriminant was >= 0 */
+  RT_STAT_EXTEND_NS = 20,  /* RT_FLAG_TIMING: summed device time of the extend launches */
+  RT_STAT_EXTEND_LAUNCHES = 21,
+  RT_STAT_SHADE_NS = 22,
+  RT_STAT_SHADE_LAUNCHES = 23,
   RT_STAT_COUNT = 24
 };
 

@@ -474,6 +474,7 @@ struct Sphere : Hittable {  // src/hittable/sphere.rs
     double c = length_squared(oc) - powi2(radius);
     double discrim = powi2(half_b) - a * c;
     if (discrim < 0.0) return none;
+    if (cx.count) cx.count->v[RT_STAT_SPHERE_ROOTS]++;
     double sqrtd = std::sqrt(discrim);
     double root = (-half_b - sqrtd) / a;
     if (!t_range.contains(root)) {
@@ -1055,27 +1056,38 @@ OptHit flat_hit(const SceneData& sc, const FlatBvh& bvh, const Ray& ray, Range t
   OptHit best;
   uint32_t best_rank = 0xFFFFFFFFu;
   if (bvh.n_nodes == 0) return best;
-  double inv[3], noi[3];
+  // f32 slab constants per axis; every step is a correctly rounded IEEE f32
+  // operation, repeated here exactly as the device performs it
+  float inv[3], noi_lo[3], noi_hi[3];
   for (int a = 0; a < 3; ++a) {
-    // a zero component: huge finite reciprocal instead of inf, so lo*inv - o*inv is never inf - inf
-    inv[a] = 1.0 / ray.direction[a];
-    if (!(std::fabs(inv[a]) <= 1e150)) inv[a] = std::copysign(1e150, ray.direction[a]);
-    noi[a] = -(ray.origin[a] * inv[a]);
+    float d32 = (float)ray.direction[a], o32 = (float)ray.origin[a];
+    float iv = 1.0f / d32;
+    if (!(std::fabs(iv) <= 1e25f)) iv = std::copysign(1e25f, d32);
+    float n = -(o32 * iv);
+    float e = std::fabs(n) * 4.76837158203125e-07f;  // 2^-21
+    inv[a] = iv;
+    noi_lo[a] = iv >= 0.0f ? n - e : n + e;
+    noi_hi[a] = iv >= 0.0f ? n + e : n - e;
   }
+  const float tmin32 = (float)t_range.start * 0.99f;
+  const float widen = 1.000003814697265625f;  // 1 + 2^-18
+  float best32 = std::numeric_limits<float>::infinity();
   uint32_t stack[64];
   int sp = 0;
   uint32_t node = 0;
   for (;;) {
     const rt_bvh_node& n = bvh.nodes[node];
     if (cx.count) cx.count->v[RT_STAT_BOX_TESTS]++;
-    double t0 = t_range.start, t1 = best.some ? best.rec.t : t_range.end;
+    float near[3], far[3];
     for (int a = 0; a < 3; ++a) {
-      double ta = std::fma((double)n.lo[a], inv[a], noi[a]);
-      double tb = std::fma((double)n.hi[a], inv[a], noi[a]);
-      t0 = std::fmax(t0, std::fmin(ta, tb));
-      t1 = std::fmin(t1, std::fmax(ta, tb));
+      float ta = std::fmaf(n.lo[a], inv[a], noi_lo[a]);
+      float tb = std::fmaf(n.hi[a], inv[a], noi_hi[a]);
+      near[a] = std::fmin(ta, tb);
+      far[a] = std::fmax(ta, tb);
     }
-    if (t0 <= t1) {
+    float t0 = std::fmax(std::fmax(near[0], near[1]), std::fmax(near[2], tmin32));
+    float t1 = std::fmin(std::fmin(far[0], far[1]), std::fmin(far[2], best32));
+    if (t0 <= t1 * widen) {
       if (n.b & 0x80000000u) {
         uint32_t axis = n.b & 3u;
         uint32_t neg = ray.direction[(int)axis] < 0.0 ? 1u : 0u;
@@ -1094,6 +1106,7 @@ OptHit flat_hit(const SceneData& sc, const FlatBvh& bvh, const Ray& ray, Range t
         if (!best.some || r.rec.t < best.rec.t || (r.rec.t == best.rec.t && it.rank < best_rank)) {
           best = r;
           best_rank = it.rank;
+          best32 = (float)r.rec.t;
         }
       }
     }

@@ -14,8 +14,10 @@ STAT_NAMES = [
     "rays", "box_tests", "sphere_tests", "msphere_tests", "rect_tests", "medium_tests",
     "op_translate", "op_rotate", "hits", "shade_miss", "shade_lambertian", "shade_metal",
     "shade_dielectric", "shade_light", "shade_isotropic", "tex_checker", "tex_perlin", "tex_image",
+    "sphere_roots", "unused19", "extend_ns", "extend_launches", "shade_ns", "shade_launches",
 ]
 RT_FLAG_STATS = 1
+RT_FLAG_TIMING = 2
 MISS_ID = 0xFFFFFFFF
 
 
@@ -152,7 +154,8 @@ _device = None
 
 
 def _open(name):
-    path = os.path.join(LIB_DIR, name)
+    # MI355RT_LIB_DIR points at an alternative build of the same libraries (A/B timing)
+    path = os.path.join(os.environ.get("MI355RT_LIB_DIR", LIB_DIR), name)
     if not os.path.exists(path):
         raise RtError(-4, f"{path} is missing: run `make` (or __graft_entry__.build()) first")
     return C.CDLL(path, mode=C.RTLD_GLOBAL)

@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <limits>
@@ -238,6 +239,7 @@ struct BuildItem {
 };
 
 struct Builder {
+  uint32_t max_leaf = 2;
   std::vector<BuildItem>& items;
   std::vector<rt_bvh_node>& nodes;
   std::vector<uint32_t>& leaf_order;  // slots in leaf order
@@ -247,9 +249,9 @@ struct Builder {
       : items(i), nodes(n), leaf_order(lo) {}
 
   // Can `count` items still be split into leaves within `levels` more interior levels?
-  static bool fits(uint64_t count, uint32_t levels) {
+  bool fits(uint64_t count, uint32_t levels) const {
     if (levels >= 40) return true;
-    return count <= ((uint64_t)kMaxLeafItems << levels);
+    return count <= ((uint64_t)max_leaf << levels);
   }
 
   void build(uint32_t node_index, size_t begin, size_t end, uint32_t depth) {
@@ -261,7 +263,7 @@ struct Builder {
     }
     store_box(bounds, nodes[node_index]);
     size_t count = end - begin;
-    if (count <= kMaxLeafItems) {
+    if (count <= max_leaf) {
       nodes[node_index].a = (uint32_t)leaf_order.size();
       nodes[node_index].b = (uint32_t)count;
       for (size_t i = begin; i < end; ++i) leaf_order.push_back(items[i].slot);
@@ -527,8 +529,27 @@ std::string flatten_scene(const rt_scene& s, FlatScene& out, int& code) {
     std::vector<uint32_t> leaf_order;
     leaf_order.reserve(build_items.size());
     Builder b(build_items, out.nodes, leaf_order);
+    if (const char* e = getenv("MI355RT_LEAF_ITEMS")) {
+      unsigned long v = strtoul(e, nullptr, 10);
+      if (v >= 1 && v <= kMaxLeafItems) b.max_leaf = (uint32_t)v;
+    }
     b.build(0, 0, build_items.size(), 0);
     out.bvh_depth = b.max_depth;
+    // Renumber breadth-first: the top of the tree becomes the head of the array,
+    // which is the part the kernels keep in LDS.  Sibling pairs stay adjacent.
+    {
+      std::vector<rt_bvh_node> bfs;
+      bfs.reserve(out.nodes.size());
+      bfs.push_back(out.nodes[0]);
+      for (size_t i = 0; i < bfs.size(); ++i) {
+        if (!(bfs[i].b & 0x80000000u)) continue;
+        uint32_t old_left = bfs[i].a;
+        bfs[i].a = (uint32_t)bfs.size();
+        bfs.push_back(out.nodes[old_left]);
+        bfs.push_back(out.nodes[old_left + 1]);
+      }
+      out.nodes.swap(bfs);
+    }
     out.prims.reserve(leaf_order.size());
     for (uint32_t slot : leaf_order) {
       out.prims.push_back(slots[slot]);

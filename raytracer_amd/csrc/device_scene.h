@@ -72,7 +72,7 @@ struct DImage {  // 16 bytes
 };
 
 const uint32_t kMaxBvhDepth = 32;   // interior levels; bounds the traversal stack
-const uint32_t kMaxLeafItems = 4;
+const uint32_t kMaxLeafItems = 8;     // upper bound; the builder's default is lower
 const uint32_t kNoPrim = 0xFFFFFFFFu;
 
 // Everything the device needs, still in host memory.

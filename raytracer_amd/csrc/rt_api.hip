@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -58,19 +59,38 @@ struct PassInfo {
 
 RT_DEV uint32_t lane_id() { return __lane_id(); }
 
-// Slot for each active lane in a queue, one atomic per wave.  Must be reached by
-// whole waves; `active` selects the lanes that append.
-RT_DEV uint32_t wave_append(uint32_t* counter, bool active) {
+// Queue appends are staged in LDS.  A returning atomic on one global word
+// saturates near 90 per microsecond on this chip, far below one per wave per
+// bin, so a workgroup collects entries in an LDS buffer (slots handed out by an
+// LDS atomic per wave: ballot + popcount) and moves them to the global queue in
+// runs of kFlushAt or more, with ONE global atomic per run and coalesced stores.
+const uint32_t kFlushAt = 512;               // flush a staged queue at this many entries
+const uint32_t kStageCap = kFlushAt + kBlock;  // a round adds at most kBlock entries
+
+// Slot in the LDS stage for each active lane.  Must be reached by whole waves.
+RT_DEV uint32_t stage_append(uint32_t* lds_count, bool active) {
   unsigned long long mask = __ballot(active);
   uint32_t base = 0;
   if (mask != 0ull) {
     uint32_t lane = lane_id();
     uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
-    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    if (lane == leader) base = atomicAdd(lds_count, (uint32_t)__popcll(mask));
     base = __shfl(base, (int)leader);
     base += (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
   }
   return base;
+}
+
+// Move `n` staged entries to the global queue.  Called by the whole workgroup
+// with a uniform n; `lds_word` is scratch for the broadcast of the reserved base.
+RT_DEV void stage_flush(const uint32_t* lds_buf, uint32_t* lds_count, uint32_t* lds_word,
+                        uint32_t* g_counter, uint32_t* g_queue, uint32_t n) {
+  if (threadIdx.x == 0) *lds_word = atomicAdd(g_counter, n);
+  __syncthreads();  // every thread has read its copy of n before this point
+  const uint32_t base = *lds_word;
+  if (threadIdx.x == 0) *lds_count = 0;
+  for (uint32_t i = threadIdx.x; i < n; i += kBlock) g_queue[base + i] = lds_buf[i];
+  __syncthreads();
 }
 
 RT_DEV void flush_stats(const Stats& st, unsigned long long* g) {
@@ -117,9 +137,12 @@ raygen_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps) {
 // --------------------------------------------------------------- extend
 template <bool STATS, bool MEDIA>
 __global__ void __launch_bounds__(kBlock)
-extend_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps, uint32_t bounce,
+extend_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_t bounce,
               unsigned long long* g_stats) {
-  __shared__ uint32_t s_stack[kMaxBvhDepth * kBlock];
+  extern __shared__ __align__(16) char smem[];
+  __shared__ uint32_t s_bin[kBins * kStageCap];
+  __shared__ uint32_t s_bin_count[kBins];
+  __shared__ uint32_t s_word;
   const uint32_t* live = pb.live[bounce & 1u];
   uint32_t* counters = pb.counters + (size_t)bounce * kCounterStride;
   const uint32_t n_live =
@@ -127,7 +150,10 @@ extend_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps, uint32_t bounce,
   Stats st;
   if (STATS) st.clear();
   const uint32_t stride = gridDim.x * kBlock;
-  // the loop bound is rounded up to whole waves so that every lane reaches the ballots
+  if (blockIdx.x * kBlock >= n_live) return;  // nothing for this workgroup: skip the staging
+  if (threadIdx.x < kBins) s_bin_count[threadIdx.x] = 0;
+  const LdsScene lds = lds_stage(sc, lay, smem, threadIdx.x, kBlock);  // ends with a barrier
+  // whole workgroups iterate together so that every lane reaches the ballots and barriers
   for (uint32_t base = blockIdx.x * kBlock; base < n_live; base += stride) {
     uint32_t i = base + threadIdx.x;
     bool valid = i < n_live;
@@ -140,21 +166,35 @@ extend_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps, uint32_t bounce,
       uint32_t x = ps.x0 + local % ps.ww, y = ps.y0 + local / ps.ww;
       DrawKey key{ps.seed, y * ps.width + x, ps.sample_base + s_local, bounce};
       stat<STATS>(st, RT_STAT_RAYS);
-      Closest h = closest_hit<STATS, MEDIA>(sc, v3(ro.x, ro.y, ro.z), v3(rdv.x, rdv.y, rdv.z), ro.w,
-                                            0.001, key, s_stack + threadIdx.x, kBlock, st);
+      Closest h = closest_hit<STATS, MEDIA>(sc, lds, v3(ro.x, ro.y, ro.z), v3(rdv.x, rdv.y, rdv.z),
+                                            ro.w, 0.001, key, st);
       pb.hit_item[path] = h.item;
       if (h.item != kNoPrim) {
         pb.ray_d[path].w = h.t;
-        bin = 1u + ((sc.prims[h.item].kind >> 8) & 7u);
+        bin = 1u + ((h.kind >> 8) & 7u);
         stat<STATS>(st, RT_STAT_HITS);
       }
     }
 #pragma unroll
     for (uint32_t k = 0; k < kBins; ++k) {
       bool mine = valid && bin == k;
-      uint32_t slot = wave_append(counters + k, mine);
-      if (mine) pb.bins[(size_t)k * pb.capacity + slot] = path;
+      uint32_t slot = stage_append(&s_bin_count[k], mine);
+      if (mine) s_bin[k * kStageCap + slot] = path;
     }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < kBins; ++k) {
+      uint32_t n = s_bin_count[k];
+      if (n >= kFlushAt)
+        stage_flush(s_bin + k * kStageCap, &s_bin_count[k], &s_word, counters + k,
+                    pb.bins + (size_t)k * pb.capacity, n);
+    }
+  }
+#pragma unroll
+  for (uint32_t k = 0; k < kBins; ++k) {
+    uint32_t n = s_bin_count[k];
+    if (n) stage_flush(s_bin + k * kStageCap, &s_bin_count[k], &s_word, counters + k,
+                       pb.bins + (size_t)k * pb.capacity, n);
   }
   if (STATS) flush_stats(st, g_stats);
 }
@@ -164,8 +204,13 @@ template <bool STATS>
 __global__ void __launch_bounds__(kBlock)
 shade_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps, uint32_t bounce, uint32_t max_depth,
              unsigned long long* g_stats) {
+  __shared__ uint32_t s_next[kStageCap];
+  __shared__ uint32_t s_next_count;
+  __shared__ uint32_t s_word;
   uint32_t* counters = pb.counters + (size_t)bounce * kCounterStride;
   uint32_t* next_live = pb.live[(bounce + 1u) & 1u];
+  if (threadIdx.x == 0) s_next_count = 0;
+  __syncthreads();
   uint32_t prefix[kBins + 1];
   prefix[0] = 0;
 #pragma unroll
@@ -252,8 +297,15 @@ shade_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps, uint32_t bounce, uint3
         }
       }
     }
-    uint32_t slot = wave_append(counters + 6, survives);
-    if (survives) next_live[slot] = path;
+    uint32_t slot = stage_append(&s_next_count, survives);
+    if (survives) s_next[slot] = path;
+    __syncthreads();
+    uint32_t n = s_next_count;
+    if (n >= kFlushAt) stage_flush(s_next, &s_next_count, &s_word, counters + 6, next_live, n);
+  }
+  {
+    uint32_t n = s_next_count;
+    if (n) stage_flush(s_next, &s_next_count, &s_word, counters + 6, next_live, n);
   }
   if (STATS) flush_stats(st, g_stats);
 }
@@ -295,8 +347,10 @@ to_float_kernel(const double* in, float* out, uint64_t n) {
 
 // ------------------------------------------------------------ first hit
 __global__ void __launch_bounds__(kBlock)
-first_hit_kernel(DeviceScene sc, PassInfo ps, uint32_t* id, double* t_out, double* normal) {
-  __shared__ uint32_t s_stack[kMaxBvhDepth * kBlock];
+first_hit_kernel(DeviceScene sc, LdsLayout lay, PassInfo ps, uint32_t* id, double* t_out,
+                 double* normal) {
+  extern __shared__ __align__(16) char smem[];
+  const LdsScene lds = lds_stage(sc, lay, smem, threadIdx.x, kBlock);
   uint32_t local = blockIdx.x * kBlock + threadIdx.x;
   if (local >= ps.n_pixels) return;
   uint32_t x = ps.x0 + local % ps.ww, y = ps.y0 + local / ps.ww;
@@ -311,8 +365,7 @@ first_hit_kernel(DeviceScene sc, PassInfo ps, uint32_t* id, double* t_out, doubl
                 offset);
   DrawKey key{0, 0, 0, 0};
   Stats st;
-  Closest h = closest_hit<false, false>(sc, origin, dir, c.time0, 0.001, key,
-                                        s_stack + threadIdx.x, kBlock, st);
+  Closest h = closest_hit<false, false>(sc, lds, origin, dir, c.time0, 0.001, key, st);
   if (h.item == kNoPrim) {
     id[local] = 0xFFFFFFFFu;
     t_out[local] = 0.0;
@@ -358,6 +411,7 @@ struct rt_ctx {
   bool have_scene = false;
   FlatScene flat;     // host copy (BVH inspection)
   DeviceScene ds{};
+  LdsLayout lds{};
   DeviceArray<float4> nodes;
   DeviceArray<DPrim> prims, boundary;
   DeviceArray<uint32_t> ranks;
@@ -375,6 +429,7 @@ struct rt_ctx {
   DeviceArray<double> accum;
   DeviceArray<unsigned long long> stats;
   uint32_t* h_probe = nullptr;  // pinned word for queue-size probes
+  std::vector<hipEvent_t> events;  // RT_FLAG_TIMING: three per bounce (before extend, between, after shade)
 };
 
 namespace {
@@ -481,6 +536,33 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats) {
   if (rc != RT_OK) return rc;
   ps.seed = p->seed;
   const bool want_stats = (p->flags & RT_FLAG_STATS) && stats;
+  const bool want_timing = (p->flags & RT_FLAG_TIMING) && stats;
+  size_t n_events = 0;
+  double extend_ms = 0.0, shade_ms = 0.0;
+  uint64_t timed_launches = 0;
+  auto stamp = [&]() -> hipError_t {
+    if (n_events == ctx->events.size()) {
+      hipEvent_t e;
+      hipError_t rc2 = hipEventCreate(&e);
+      if (rc2 != hipSuccess) return rc2;
+      ctx->events.push_back(e);
+    }
+    return hipEventRecord(ctx->events[n_events++], ctx->stream);
+  };
+  // elapsed times of the recorded triples; the stream must be idle
+  auto drain = [&]() -> hipError_t {
+    for (size_t i = 0; i + 2 < n_events; i += 3) {
+      float a = 0.f, b = 0.f;
+      hipError_t rc2 = hipEventElapsedTime(&a, ctx->events[i], ctx->events[i + 1]);
+      if (rc2 == hipSuccess) rc2 = hipEventElapsedTime(&b, ctx->events[i + 1], ctx->events[i + 2]);
+      if (rc2 != hipSuccess) return rc2;
+      extend_ms += a;
+      shade_ms += b;
+      ++timed_launches;
+    }
+    n_events = 0;
+    return hipSuccess;
+  };
   const uint32_t n_samples = p->sample_end - p->sample_begin;
   const uint64_t n_pix = ps.n_pixels;
   if (n_pix > ctx->max_paths)
@@ -507,8 +589,11 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats) {
   rc = ensure_paths(ctx, n_pix * per_pass, p->max_depth);
   if (rc != RT_OK) return rc;
   const PathBuffers pb = ctx->pb;
-  const uint32_t max_grid = ctx->n_cus * 8u;
+  uint32_t blocks_per_cu = 16u;
+  if (const char* e = getenv("MI355RT_BLOCKS_PER_CU")) blocks_per_cu = (uint32_t)strtoul(e, nullptr, 10);
+  const uint32_t max_grid = ctx->n_cus * std::max(1u, blocks_per_cu);
   const bool media = ctx->flat.has_media;
+  const LdsLayout lds = ctx->lds;
 
   for (uint32_t done = 0; done < n_samples; done += per_pass) {
     ps.samples = std::min(per_pass, n_samples - done);
@@ -522,15 +607,19 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats) {
     uint32_t grid = std::min(blocks_for(ps.n_paths), max_grid);
     for (uint32_t b = 0; b < p->max_depth; ++b) {
       unsigned long long* gs = ctx->stats.p;
+      if (want_timing) RT_HIP(ctx, stamp());
       if (want_stats) {
-        if (media) extend_kernel<true, true><<<grid, kBlock, 0, ctx->stream>>>(ctx->ds, pb, ps, b, gs);
-        else extend_kernel<true, false><<<grid, kBlock, 0, ctx->stream>>>(ctx->ds, pb, ps, b, gs);
+        if (media) extend_kernel<true, true><<<grid, kBlock, lds.bytes, ctx->stream>>>(ctx->ds, lds, pb, ps, b, gs);
+        else extend_kernel<true, false><<<grid, kBlock, lds.bytes, ctx->stream>>>(ctx->ds, lds, pb, ps, b, gs);
+        if (want_timing) RT_HIP(ctx, stamp());
         shade_kernel<true><<<grid, kBlock, 0, ctx->stream>>>(ctx->ds, pb, ps, b, p->max_depth, gs);
       } else {
-        if (media) extend_kernel<false, true><<<grid, kBlock, 0, ctx->stream>>>(ctx->ds, pb, ps, b, gs);
-        else extend_kernel<false, false><<<grid, kBlock, 0, ctx->stream>>>(ctx->ds, pb, ps, b, gs);
+        if (media) extend_kernel<false, true><<<grid, kBlock, lds.bytes, ctx->stream>>>(ctx->ds, lds, pb, ps, b, gs);
+        else extend_kernel<false, false><<<grid, kBlock, lds.bytes, ctx->stream>>>(ctx->ds, lds, pb, ps, b, gs);
+        if (want_timing) RT_HIP(ctx, stamp());
         shade_kernel<false><<<grid, kBlock, 0, ctx->stream>>>(ctx->ds, pb, ps, b, p->max_depth, gs);
       }
+      if (want_timing) RT_HIP(ctx, stamp());
       // every 8 bounces look at the live count: stop when no path is left and
       // shrink the grid as the queues drain
       if ((b & 7u) == 7u && b + 1 < p->max_depth) {
@@ -538,6 +627,7 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats) {
                                    sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         uint32_t live = *ctx->h_probe;
+        if (want_timing) RT_HIP(ctx, drain());
         if (live == 0) break;
         grid = std::max(1u, std::min(blocks_for(live), max_grid));
       }
@@ -549,6 +639,15 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats) {
   if (want_stats)
     RT_HIP(ctx, hipMemcpy(stats, ctx->stats.p, RT_STAT_COUNT * sizeof(uint64_t),
                           hipMemcpyDeviceToHost));
+  else if (want_timing)
+    std::memset(stats, 0, RT_STAT_COUNT * sizeof(uint64_t));
+  if (want_timing) {
+    RT_HIP(ctx, drain());
+    stats[RT_STAT_EXTEND_NS] = (uint64_t)(extend_ms * 1e6);
+    stats[RT_STAT_SHADE_NS] = (uint64_t)(shade_ms * 1e6);
+    stats[RT_STAT_EXTEND_LAUNCHES] = timed_launches;
+    stats[RT_STAT_SHADE_LAUNCHES] = timed_launches;
+  }
   return RT_OK;
 }
 
@@ -625,6 +724,31 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* scene) {
   ds.has_media = f.has_media ? 1u : 0u;
   ds.cam = f.camera;
   std::memcpy(ds.bg, f.background, sizeof ds.bg);
+  // LDS plan per 256-thread workgroup: the traversal stack (one entry per BVH level),
+  // then as many top-of-tree nodes as fit, then leaf slots with what is left.
+  {
+    uint32_t budget = 20u * 1024u;
+    if (const char* e = getenv("MI355RT_LDS_BYTES")) budget = (uint32_t)strtoul(e, nullptr, 10);
+    budget = std::min(budget, 160u * 1024u);
+    LdsLayout& l = ctx->lds;
+    l.stack_depth = std::max(1u, f.bvh_depth);
+    uint32_t used = l.stack_depth * kBlock * (uint32_t)sizeof(uint32_t);
+    uint32_t room = budget > used ? budget - used : 0u;
+    l.n_nodes = std::min<uint32_t>((uint32_t)f.nodes.size(), room / 32u);
+    room -= l.n_nodes * 32u;
+    l.n_prims = std::min<uint32_t>((uint32_t)f.prims.size(), room / 64u);
+    if (const char* e = getenv("MI355RT_LDS_PRIMS")) l.n_prims = std::min<uint32_t>(l.n_prims, (uint32_t)strtoul(e, nullptr, 10));
+    l.bytes = used + l.n_nodes * 32u + l.n_prims * 64u;
+  }
+  if (ctx->lds.bytes > 48u * 1024u) {
+    int bytes = (int)ctx->lds.bytes;
+    const hipFuncAttribute attr = hipFuncAttributeMaxDynamicSharedMemorySize;
+    RT_HIP(ctx, hipFuncSetAttribute((const void*)extend_kernel<false, false>, attr, bytes));
+    RT_HIP(ctx, hipFuncSetAttribute((const void*)extend_kernel<false, true>, attr, bytes));
+    RT_HIP(ctx, hipFuncSetAttribute((const void*)extend_kernel<true, false>, attr, bytes));
+    RT_HIP(ctx, hipFuncSetAttribute((const void*)extend_kernel<true, true>, attr, bytes));
+    RT_HIP(ctx, hipFuncSetAttribute((const void*)first_hit_kernel, attr, bytes));
+  }
   ctx->have_scene = true;
   return RT_OK;
 }
@@ -695,7 +819,8 @@ int rt_first_hit(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_window* 
   if (e == hipSuccess) e = hipMalloc((void**)&d_t, n * sizeof(double));
   if (e == hipSuccess) e = hipMalloc((void**)&d_n, n * 3 * sizeof(double));
   if (e == hipSuccess) {
-    first_hit_kernel<<<blocks_for(n), kBlock, 0, ctx->stream>>>(ctx->ds, ps, d_id, d_t, d_n);
+    first_hit_kernel<<<blocks_for(n), kBlock, ctx->lds.bytes, ctx->stream>>>(ctx->ds, ctx->lds, ps, d_id,
+                                                                             d_t, d_n);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -770,6 +895,7 @@ void rt_destroy(rt_ctx* ctx) {
   ctx->accum.release();
   ctx->stats.release();
   if (ctx->h_probe) (void)hipHostFree(ctx->h_probe);
+  for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

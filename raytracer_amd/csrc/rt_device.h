@@ -200,13 +200,16 @@ RT_DEV V3 moving_center(const DeviceScene& sc, const DPrim& pr, double time) {  
 RT_DEV bool in_range(double t, double lo, double hi) { return lo <= t && t < hi; }  // Range::contains
 
 // Sphere::hit up to the root (sphere.rs:32-51).
-RT_DEV bool sphere_t(V3 c, double radius, V3 o, V3 d, double tmin, double tmax, double& t) {
+template <bool STATS>
+RT_DEV bool sphere_t(V3 c, double radius, V3 o, V3 d, double tmin, double tmax, double& t,
+                     Stats& st) {
   V3 oc = vsub(o, c);
   double a = vlen2(d);
   double half_b = vdot(oc, d);
   double cc = vlen2(oc) - radius * radius;
   double discrim = half_b * half_b - a * cc;
   if (discrim < 0.0) return false;
+  stat<STATS>(st, RT_STAT_SPHERE_ROOTS);
   double sqrtd = sqrt(discrim);
   double root = (-half_b - sqrtd) / a;
   if (!in_range(root, tmin, tmax)) {
@@ -241,11 +244,11 @@ RT_DEV bool base_prim_t(const DeviceScene& sc, const DPrim& pr, V3 o, V3 d, doub
   uint32_t kind = pr.kind & 15u;
   if (kind == DP_SPHERE) {
     stat<STATS>(st, RT_STAT_SPHERE_TESTS);
-    return sphere_t(v3(pr.p[0], pr.p[1], pr.p[2]), pr.p[3], o, d, tmin, tmax, t);
+    return sphere_t<STATS>(v3(pr.p[0], pr.p[1], pr.p[2]), pr.p[3], o, d, tmin, tmax, t, st);
   }
   if (kind == DP_MOVING_SPHERE) {
     stat<STATS>(st, RT_STAT_MSPHERE_TESTS);
-    return sphere_t(moving_center(sc, pr, time), pr.p[3], o, d, tmin, tmax, t);
+    return sphere_t<STATS>(moving_center(sc, pr, time), pr.p[3], o, d, tmin, tmax, t, st);
   }
   stat<STATS>(st, RT_STAT_RECT_TESTS);
   return rect_t(pr, o, d, tmin, tmax, t);
@@ -341,36 +344,115 @@ RT_DEV Record make_record(const DeviceScene& sc, const DPrim& pr, V3 o, V3 d, do
 }
 
 // -------------------------------------------------------------- traversal
-// 1/d for the slab test.  A zero (or denormal) component would give an infinite
-// reciprocal and inf - inf = NaN in `lo * inv - o * inv`; a huge finite value
-// keeps every product finite and still puts the slab planes beyond any real t.
-RT_DEV double cull_reciprocal(double d) {
-  const double big = 1e150;
-  double inv = 1.0 / d;
-  return fabs(inv) <= big ? inv : copysign(big, d);
+// Per-ray constants of the f32 slab test, one set per axis.
+//
+// The test only culls, so it runs in f32 with FMA; what makes it safe is that it
+// is CONSERVATIVE against the exact slab parameters T = (b - o) / d:
+//   inv = fl(1 / fl32(d)) carries a relative error < 2^-22, the final FMA another
+//   2^-24: both scale T and are absorbed by comparing t0 <= t1 * (1 + 2^-18);
+//   rounding o to f32 and rounding -o*inv shift T by at most 2^-23 |o inv|: the
+//   pad E = 2^-21 |o inv| is subtracted on the entry side and added on the exit
+//   side (which plane is which follows the sign of inv).
+// A zero or denormal d would give inv = inf and inf - inf = NaN; inv is clamped
+// to +-1e25, which still puts both planes beyond every real t.
+// Every operation is a correctly rounded IEEE f32 operation, so a CPU can
+// reproduce the decisions bit for bit.
+struct CullAxis {
+  float inv, noi_lo, noi_hi;
+};
+RT_DEV CullAxis cull_axis(double o, double d) {
+  float d32 = (float)d, o32 = (float)o;
+  float inv = __fdiv_rn(1.0f, d32);
+  if (!(fabsf(inv) <= 1e25f)) inv = copysignf(1e25f, d32);
+  float noi = -(o32 * inv);
+  float e = fabsf(noi) * 4.76837158203125e-07f;  // 2^-21
+  CullAxis c;
+  c.inv = inv;
+  c.noi_lo = inv >= 0.0f ? noi - e : noi + e;
+  c.noi_hi = inv >= 0.0f ? noi + e : noi - e;
+  return c;
 }
 
 struct Closest {
   double t;
   uint32_t item;  // leaf slot, or kNoPrim
+  uint32_t kind;  // kind word of that slot's record
 };
+
+// The head of the node array (breadth-first order, so the top of the tree) and
+// the head of the leaf-slot array, staged in LDS by each workgroup, plus the
+// traversal stack.  All three share one dynamic LDS allocation laid out by
+// LdsLayout on the host.
+struct LdsLayout {
+  uint32_t n_nodes;      // nodes [0, n_nodes) are in LDS
+  uint32_t n_prims;      // leaf slots [0, n_prims) are in LDS
+  uint32_t stack_depth;  // stack entries per lane
+  uint32_t bytes;        // total dynamic LDS bytes per workgroup
+};
+struct LdsScene {
+  const float4* nodes;
+  const float4* prims;  // 4 x float4 per DPrim
+  uint32_t* stack;      // this lane's column, entries `stack_stride` words apart
+  uint32_t n_nodes, n_prims, stack_stride;
+};
+
+// Carve the workgroup's dynamic LDS and stage the scene head into it.  Every
+// thread of the workgroup must call this (it ends with a barrier).
+RT_DEV LdsScene lds_stage(const DeviceScene& sc, const LdsLayout& lay, char* smem, uint32_t tid,
+                          uint32_t block) {
+  float4* nodes = (float4*)smem;
+  float4* prims = nodes + 2u * lay.n_nodes;
+  uint32_t* stack = (uint32_t*)(prims + 4u * lay.n_prims);
+  const float4* gp = (const float4*)sc.prims;
+  for (uint32_t i = tid; i < 2u * lay.n_nodes; i += block) nodes[i] = sc.nodes[i];
+  for (uint32_t i = tid; i < 4u * lay.n_prims; i += block) prims[i] = gp[i];
+  __syncthreads();
+  LdsScene l;
+  l.nodes = nodes;
+  l.prims = prims;
+  l.stack = stack + tid;
+  l.n_nodes = lay.n_nodes;
+  l.n_prims = lay.n_prims;
+  l.stack_stride = block;
+  return l;
+}
+
+RT_DEV DPrim load_prim(const DeviceScene& sc, const LdsScene& lds, uint32_t slot) {
+  union {
+    float4 q[4];
+    DPrim p;
+  } u;
+  if (slot < lds.n_prims) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) u.q[k] = lds.prims[4u * slot + k];
+  } else {
+    const float4* g = (const float4*)(sc.prims + slot);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) u.q[k] = g[k];
+  }
+  return u.p;
+}
 
 // world.hit(ray, tmin..inf): closest t over the flattened BVH.  Each visited node
 // is slab-tested against [tmin, best t]; an interior node pushes its far child
 // (by direction sign on the split axis) and continues with the near one.  Equal
-// t resolves to the lower rank.  `stack` is this lane's column of the LDS stack,
-// entries `stride` words apart.
+// t resolves to the lower rank.
 template <bool STATS, bool MEDIA>
-RT_DEV Closest closest_hit(const DeviceScene& sc, V3 o, V3 d, double time, double tmin,
-                           const DrawKey& key, uint32_t* stack, uint32_t stride, Stats& st) {
+RT_DEV Closest closest_hit(const DeviceScene& sc, const LdsScene& lds, V3 o, V3 d, double time,
+                           double tmin, const DrawKey& key, Stats& st) {
+  uint32_t* stack = lds.stack;
+  const uint32_t stride = lds.stack_stride;
   const double inf = __longlong_as_double(0x7FF0000000000000ll);
   Closest best;
   best.t = inf;
   best.item = kNoPrim;
+  best.kind = 0;
   if (sc.n_nodes == 0) return best;
-  // culling arithmetic: 1/d and -o/d once per ray, one FMA per slab plane
-  double ix = cull_reciprocal(d.x), iy = cull_reciprocal(d.y), iz = cull_reciprocal(d.z);
-  double nx = -(o.x * ix), ny = -(o.y * iy), nz = -(o.z * iz);
+  // culling arithmetic: once per ray, then one FMA per slab plane
+  const CullAxis cx = cull_axis(o.x, d.x), cy = cull_axis(o.y, d.y), cz = cull_axis(o.z, d.z);
+  const float tmin32 = (float)tmin * 0.99f;
+  const float kWiden = 1.000003814697265625f;  // 1 + 2^-18
+  float best32 = __int_as_float(0x7F800000);
   uint32_t sp = 0;
   uint32_t node = 0;
   const uint32_t kNone = 0xFFFFFFFFu;
@@ -378,16 +460,22 @@ RT_DEV Closest closest_hit(const DeviceScene& sc, V3 o, V3 d, double time, doubl
     // walk down until a leaf passes its box test
     uint32_t leaf_first = 0, leaf_count = 0;
     while (node != kNone) {
-      float4 n0 = sc.nodes[2 * node];
-      float4 n1 = sc.nodes[2 * node + 1];
+      float4 n0, n1;
+      if (node < lds.n_nodes) {
+        n0 = lds.nodes[2 * node];
+        n1 = lds.nodes[2 * node + 1];
+      } else {
+        n0 = sc.nodes[2 * node];
+        n1 = sc.nodes[2 * node + 1];
+      }
       stat<STATS>(st, RT_STAT_BOX_TESTS);
-      double ax = __builtin_fma((double)n0.x, ix, nx), bx = __builtin_fma((double)n0.w, ix, nx);
-      double ay = __builtin_fma((double)n0.y, iy, ny), by = __builtin_fma((double)n1.x, iy, ny);
-      double az = __builtin_fma((double)n0.z, iz, nz), bz = __builtin_fma((double)n1.y, iz, nz);
-      double t0 = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmax(fmin(az, bz), tmin));
-      double t1 = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmin(fmax(az, bz), best.t));
+      float ax = fmaf(n0.x, cx.inv, cx.noi_lo), bx = fmaf(n0.w, cx.inv, cx.noi_hi);
+      float ay = fmaf(n0.y, cy.inv, cy.noi_lo), by = fmaf(n1.x, cy.inv, cy.noi_hi);
+      float az = fmaf(n0.z, cz.inv, cz.noi_lo), bz = fmaf(n1.y, cz.inv, cz.noi_hi);
+      float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin32));
+      float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best32));
       uint32_t a = __float_as_uint(n1.z), b = __float_as_uint(n1.w);
-      if (t0 <= t1) {
+      if (t0 <= t1 * kWiden) {
         if (b & 0x80000000u) {
           uint32_t axis = b & 3u;
           uint32_t neg = vget(d, axis) < 0.0 ? 1u : 0u;
@@ -405,7 +493,7 @@ RT_DEV Closest closest_hit(const DeviceScene& sc, V3 o, V3 d, double time, doubl
     }
     for (uint32_t k = 0; k < leaf_count; ++k) {
       uint32_t slot = leaf_first + k;
-      const DPrim pr = sc.prims[slot];
+      const DPrim pr = load_prim(sc, lds, slot);
       double t;
       bool hit;
       if (MEDIA && (pr.kind & 15u) == DP_MEDIUM)
@@ -419,6 +507,8 @@ RT_DEV Closest closest_hit(const DeviceScene& sc, V3 o, V3 d, double time, doubl
                            sc.ranks[slot] < sc.ranks[best.item])) {
           best.t = t;
           best.item = slot;
+          best.kind = pr.kind;
+          best32 = (float)t;
         }
       }
     }

@@ -1,0 +1,30 @@
+"""Sample-range sharding over ranks (one process per GPU) and the one collective.
+
+Every pixel-sample is independent (src/main.rs:87-97); the only coupling is the
+per-pixel sum (main.rs:97).  Rank r of W renders samples
+[begin + r*n/W, begin + (r+1)*n/W) of every pixel into its own float32 buffer;
+one reduce(sum) to rank 0 adds the buffers.  Draws are addressed by
+(pixel, sample), so the union of samples is the same for every W.
+"""
+
+
+def shard_samples(sample_begin, sample_end, rank, world):
+    """The half-open sample range of `rank`; ranges tile [begin, end) exactly."""
+    n = sample_end - sample_begin
+    lo = sample_begin + (n * rank) // world
+    hi = sample_begin + (n * (rank + 1)) // world
+    return lo, hi
+
+
+def render_sharded(render_fn, out, sample_begin, sample_end, rank, world, dist=None):
+    """Render this rank's share into `out` and reduce onto rank 0.
+
+    render_fn(lo, hi, out): fills `out` (a tensor on this rank's device) with the
+    float32 sums over samples [lo, hi).  `dist` is torch.distributed (initialised)
+    or None for a single process.
+    """
+    lo, hi = shard_samples(sample_begin, sample_end, rank, world)
+    render_fn(lo, hi, out)
+    if dist is not None and world > 1:
+        dist.reduce(out, dst=0, op=dist.ReduceOp.SUM)
+    return lo, hi

@@ -48,23 +48,36 @@ class Context:
             return p.height, p.width
         return p.window.h, p.window.w
 
-    def render(self, p, dtype=np.float32, stats=False):
-        """Sums of ray_color over [sample_begin, sample_end) per window pixel, (h, w, 3)."""
+    def render(self, p, dtype=np.float32, stats=False, timing=False):
+        """Sums of ray_color over [sample_begin, sample_end) per window pixel, (h, w, 3).
+
+        stats / timing: also return the RT_STAT_* array (operation counts from the
+        instrumented kernels / device time of the extend and shade launches).
+        """
         L = abi.device_lib()
         h, w = self._shape(p)
         out = np.empty((h, w, 3), dtype=dtype)
         st = None
         if stats:
             p.flags |= abi.RT_FLAG_STATS
+        if timing:
+            p.flags |= abi.RT_FLAG_TIMING
+        stats = stats or timing
+        if stats:
             st = np.zeros(abi.RT_STAT_COUNT, dtype=np.uint64)
         fn = L.rt_render if dtype == np.float32 else L.rt_render_f64
         self._check(fn(self._h, C.byref(p), out.ctypes.data, st.ctypes.data if stats else None))
         return (out, st) if stats else out
 
-    def render_into(self, p, device_ptr):
+    def render_into(self, p, device_ptr, timing=False):
         """Same sums as float32 into device memory at `device_ptr` (e.g. tensor.data_ptr())."""
+        st = None
+        if timing:
+            p.flags |= abi.RT_FLAG_TIMING
+            st = np.zeros(abi.RT_STAT_COUNT, dtype=np.uint64)
         self._check(abi.device_lib().rt_render_device(self._h, C.byref(p), C.c_void_p(device_ptr),
-                                                      None))
+                                                      st.ctypes.data if timing else None))
+        return st
 
     def first_hit(self, width, height, window=None):
         L = abi.device_lib()

@@ -1,0 +1,43 @@
+"""Time the render under different settings read from the environment at upload.
+
+usage: python tools/perf_sweep.py scene spp width height  VAR=v1,v2,...  [VAR2=...]
+"""
+import itertools
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from raytracer_amd.render import Context  # noqa: E402
+from raytracer_amd.scene import HostScene  # noqa: E402
+
+name, spp, w, h = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+sweeps = [a.split("=") for a in sys.argv[5:]]
+keys = [k for k, _ in sweeps]
+values = [v.split(",") for _, v in sweeps]
+scene = HostScene.load_frozen(os.path.join(ROOT, "tests", "golden", name + ".rtscene"))
+scene.set_image(w, h)
+ref = None
+for combo in itertools.product(*values) if values else [()]:
+    for k, v in zip(keys, combo):
+        if v == "-":
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+    ctx = Context(0)
+    ctx.upload(scene)
+    best = 1e9
+    for rep in range(3):
+        p = ctx.params(w, h, 0, spp, scene.max_depth, seed=1)
+        t0 = time.perf_counter()
+        img, st = ctx.render(p, dtype=np.float32, timing=True)
+        best = min(best, time.perf_counter() - t0)
+    chk = float(img.astype(np.float64).sum())
+    if ref is None:
+        ref = chk
+    print(dict(zip(keys, combo)), f"{best * 1e3:8.1f} ms  {w * h * spp / best / 1e6:8.1f} Mps/s  "
+          f"extend {st[20] / 1e6:7.1f} ms shade {st[22] / 1e6:7.1f} ms  same_image={chk == ref}", flush=True)
+    ctx.close()
