@@ -1,0 +1,120 @@
+"""The C-ABI libraries: exported symbols, loud failure without a device, BVH invariants."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from raytracer_amd import abi
+from raytracer_amd.render import Context, build_bvh
+from raytracer_amd.scene import HostScene
+import pyoracle as po
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "mi355rt.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rt_(?:host_)?[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported():
+    names = declared_functions()
+    assert len(names) >= 25
+    host, dev = abi.host_lib(), abi.device_lib()
+    for n in names:
+        lib = host if n.startswith("rt_host_") else dev
+        assert hasattr(lib, n), f"{n} is declared in include/mi355rt.h but not exported"
+    assert set(abi.HOST_SYMBOLS + abi.DEVICE_SYMBOLS) == set(names)
+
+
+def test_struct_sizes_match_the_header():
+    # sizes the frozen format and the device upload rely on
+    assert C.sizeof(abi.Prim) == 104 and C.sizeof(abi.Op) == 32 and C.sizeof(abi.Object) == 96
+    assert C.sizeof(abi.Material) == 40 and C.sizeof(abi.Texture) == 48
+    assert C.sizeof(abi.Perlin) == 256 * 24 + 3 * 1024 and C.sizeof(abi.BvhNode) == 32
+    assert C.sizeof(abi.RenderParams) == 48 and C.sizeof(abi.Camera) == 168
+
+
+def test_no_device_means_an_error_not_a_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a device is present")
+    with pytest.raises(abi.RtError):
+        Context(device=0)
+
+
+def test_upload_rejects_malformed_scenes(golden_dir):
+    s = HostScene.load_frozen(os.path.join(golden_dir, "material_demo.rtscene"))
+    v = s.view
+    saved = v.prims[0].material
+    v.prims[0].material = 9999
+    h = C.c_void_p()
+    assert abi.device_lib().rt_bvh_build(s.view_ptr, C.byref(h)) == -1
+    v.prims[0].material = saved
+    assert abi.device_lib().rt_bvh_build(s.view_ptr, C.byref(h)) == 0
+    abi.device_lib().rt_bvh_free(h)
+
+
+@pytest.mark.parametrize("name", ["material_demo", "book_cover", "cornell", "book2", "motion_blur"])
+def test_bvh_invariants(golden_dir, name):
+    s = HostScene.load_frozen(os.path.join(golden_dir, name + ".rtscene"))
+    nodes, items, depth = build_bvh(s)
+    v = s.view
+    assert depth <= 32
+    # every primitive of every non-medium object, and every medium object, appears exactly once
+    expect = set()
+    for i in range(v.n_objects):
+        o = v.objects[i]
+        if o.is_medium:
+            expect.add((i, 0xFFFFFFFF))
+        else:
+            expect.update((i, o.first_prim + k) for k in range(o.prim_count))
+    got = [(int(it["object"]), int(it["prim"])) for it in items]
+    assert len(got) == len(set(got)) and set(got) == expect
+    # ranks follow the oracle's reference-topology preference order
+    ranks = po.Oracle(s.view_ptr).ranks(v.n_objects)
+    order = np.argsort(ranks)
+    base, run = {}, 0
+    for obj in order:
+        base[int(obj)] = run
+        run += v.objects[int(obj)].prim_count
+    for it in items:
+        o = v.objects[int(it["object"])]
+        k = 0 if it["prim"] == 0xFFFFFFFF else int(it["prim"]) - o.first_prim
+        assert int(it["rank"]) == base[int(it["object"])] + k
+    # children lie inside their parent, sibling pairs are adjacent, leaves tile the item array
+    seen_items = np.zeros(len(items), dtype=bool)
+    stack = [(0, 0)]
+    max_seen = 0
+    while stack:
+        n, d = stack.pop()
+        max_seen = max(max_seen, d)
+        node = nodes[n]
+        if node["b"] & 0x80000000:
+            for c in (int(node["a"]), int(node["a"]) + 1):
+                assert c > n  # breadth-first numbering
+                assert np.all(nodes[c]["lo"] >= node["lo"]) and np.all(nodes[c]["hi"] <= node["hi"])
+                stack.append((c, d + 1))
+        else:
+            a, b = int(node["a"]), int(node["b"])
+            assert 1 <= b <= 8 and not seen_items[a:a + b].any()
+            seen_items[a:a + b] = True
+    assert seen_items.all() and max_seen == depth
+
+
+@pytest.mark.parametrize("name,size,spp", [("book_cover", (96, 54), 2), ("cornell", (40, 40), 4),
+                                           ("book2", (64, 36), 1), ("medium_demo", (64, 36), 2),
+                                           ("motion_blur", (80, 25), 2)])
+def test_flat_traversal_equals_reference_topology(golden_dir, name, size, spp):
+    """Conservative culling + rank tie-breaks give the reference's answer (checked on the CPU)."""
+    s = HostScene.load_frozen(os.path.join(golden_dir, name + ".rtscene"))
+    s.set_image(*size)
+    nodes, items, _ = build_bvh(s)
+    o = po.Oracle(s.view_ptr)
+    p = po.make_params(size[0], size[1], 0, spp, s.max_depth, 3)
+    ref = o.render(p, po.MODE_ITERATIVE, threads=4)
+    flat = o.render(p, po.MODE_FLAT, bvh=(nodes, items), threads=4)
+    assert np.array_equal(ref, flat)

