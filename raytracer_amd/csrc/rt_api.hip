@@ -200,7 +200,11 @@ extend_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32
 }
 
 // ---------------------------------------------------------------- shade
-template <bool STATS>
+// One instantiation per bin (BIN 0 = misses, BIN 1 + k = material kind k), each
+// launched over its own queue: a kernel carries only its material's code and
+// registers.  SOLID: every texture of the scene is a SolidColor (no texture walk,
+// no (u, v)).
+template <int BIN, bool STATS, bool SOLID>
 __global__ void __launch_bounds__(kBlock)
 shade_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps, uint32_t bounce, uint32_t max_depth,
              unsigned long long* g_stats) {
@@ -209,13 +213,11 @@ shade_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps, uint32_t bounce, uint3
   __shared__ uint32_t s_word;
   uint32_t* counters = pb.counters + (size_t)bounce * kCounterStride;
   uint32_t* next_live = pb.live[(bounce + 1u) & 1u];
+  const uint32_t total = counters[BIN];
+  if (blockIdx.x * kBlock >= total) return;
+  const uint32_t* queue = pb.bins + (size_t)BIN * pb.capacity;
   if (threadIdx.x == 0) s_next_count = 0;
   __syncthreads();
-  uint32_t prefix[kBins + 1];
-  prefix[0] = 0;
-#pragma unroll
-  for (uint32_t k = 0; k < kBins; ++k) prefix[k + 1] = prefix[k] + counters[k];
-  const uint32_t total = prefix[kBins];
   Stats st;
   if (STATS) st.clear();
   const uint32_t stride = gridDim.x * kBlock;
@@ -225,38 +227,37 @@ shade_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps, uint32_t bounce, uint3
     bool survives = false;
     uint32_t path = 0;
     if (valid) {
-      uint32_t bin = 0;
-#pragma unroll
-      for (uint32_t k = 1; k < kBins; ++k) bin += i >= prefix[k] ? 1u : 0u;
-      path = pb.bins[(size_t)bin * pb.capacity + (i - prefix[bin])];
+      path = queue[i];
       double4 bt = pb.beta[path];
       V3 beta = v3(bt.x, bt.y, bt.z);
-      if (bin == 0) {
+      if (BIN == 0) {
         // miss: the recursion returns `background` (main.rs:137-139)
         stat<STATS>(st, RT_STAT_SHADE_MISS);
         double4 L = pb.radiance[path];
         V3 add = vmul(beta, v3(sc.bg));
         pb.radiance[path] = make_double4(L.x + add.x, L.y + add.y, L.z + add.z, 0.0);
       } else {
-        stat<STATS>(st, RT_STAT_SHADE_LAMBERTIAN + (int)(bin - 1u));
+        const uint32_t kind = (uint32_t)BIN - 1u;
+        stat<STATS>(st, RT_STAT_SHADE_LAMBERTIAN + (int)kind);
         double4 ro = pb.ray_o[path];
         double4 rdv = pb.ray_d[path];
         V3 o = v3(ro.x, ro.y, ro.z), d = v3(rdv.x, rdv.y, rdv.z);
         double time = ro.w, t = rdv.w;
         const DPrim pr = sc.prims[pb.hit_item[path]];
         const DMaterial m = sc.materials[pr.material];
-        bool want_uv = (pr.kind >> 11) & 1u;
-        Record rec = make_record(sc, pr, o, d, time, t, want_uv);
+        const bool textured = kind == RT_MAT_LAMBERTIAN || kind == RT_MAT_DIFFUSE_LIGHT ||
+                              kind == RT_MAT_ISOTROPIC;
+        bool want_uv = textured && ((pr.kind >> 11) & 1u);
+        Record rec = make_record<!SOLID>(sc, pr, o, d, time, t, want_uv);
         uint32_t s_local = path / ps.n_pixels, local = path % ps.n_pixels;
         uint32_t x = ps.x0 + local % ps.ww, y = ps.y0 + local / ps.ww;
         DrawKey key{ps.seed, y * ps.width + x, ps.sample_base + s_local, bounce};
         V3 attenuation = v3(0.0, 0.0, 0.0), dir = v3(0.0, 0.0, 0.0);
         bool scattered = false;
-        const uint32_t kind = bin - 1u;
         if (kind == RT_MAT_LAMBERTIAN) {  // lambertian.rs:13-25
           dir = vadd(rec.normal, rand_unit_vector(key));
           if (vnear_zero(dir)) dir = rec.normal;
-          attenuation = texture_value<STATS>(sc, m.texture, rec.u, rec.v, rec.p, st);
+          attenuation = texture_value<STATS, SOLID>(sc, m.texture, rec.u, rec.v, rec.p, st);
           scattered = true;
         } else if (kind == RT_MAT_METAL) {  // metal.rs:12-28
           V3 reflected = vreflect(vunit(d), rec.normal);
@@ -278,12 +279,12 @@ shade_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps, uint32_t bounce, uint3
           attenuation = v3(1.0, 1.0, 1.0);
           scattered = true;
         } else if (kind == RT_MAT_DIFFUSE_LIGHT) {  // emissive.rs:10-12; never scatters
-          V3 emitted = texture_value<STATS>(sc, m.texture, rec.u, rec.v, rec.p, st);
+          V3 emitted = texture_value<STATS, SOLID>(sc, m.texture, rec.u, rec.v, rec.p, st);
           double4 L = pb.radiance[path];
           V3 add = vmul(beta, emitted);
           pb.radiance[path] = make_double4(L.x + add.x, L.y + add.y, L.z + add.z, 0.0);
         } else {  // isotropic.rs:10-17
-          attenuation = texture_value<STATS>(sc, m.texture, rec.u, rec.v, rec.p, st);
+          attenuation = texture_value<STATS, SOLID>(sc, m.texture, rec.u, rec.v, rec.p, st);
           dir = rand_unit_vector(key);
           scattered = true;
         }
@@ -297,17 +298,32 @@ shade_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps, uint32_t bounce, uint3
         }
       }
     }
-    uint32_t slot = stage_append(&s_next_count, survives);
-    if (survives) s_next[slot] = path;
-    __syncthreads();
-    uint32_t n = s_next_count;
-    if (n >= kFlushAt) stage_flush(s_next, &s_next_count, &s_word, counters + 6, next_live, n);
+    if (BIN != 0 && BIN != 1 + RT_MAT_DIFFUSE_LIGHT) {  // misses and lights end their paths
+      uint32_t slot = stage_append(&s_next_count, survives);
+      if (survives) s_next[slot] = path;
+      __syncthreads();
+      uint32_t n = s_next_count;
+      if (n >= kFlushAt) stage_flush(s_next, &s_next_count, &s_word, counters + 6, next_live, n);
+    }
   }
-  {
+  if (BIN != 0 && BIN != 1 + RT_MAT_DIFFUSE_LIGHT) {
     uint32_t n = s_next_count;
     if (n) stage_flush(s_next, &s_next_count, &s_word, counters + 6, next_live, n);
   }
   if (STATS) flush_stats(st, g_stats);
+}
+
+template <bool STATS, bool SOLID>
+void launch_shade(uint32_t bins_present, uint32_t grid, hipStream_t stream, const DeviceScene& ds,
+                  const PathBuffers& pb, const PassInfo& ps, uint32_t b, uint32_t max_depth,
+                  unsigned long long* gs) {
+  // bin 0 (misses) always exists; the others only if the scene has that material kind
+  shade_kernel<0, STATS, SOLID><<<grid, kBlock, 0, stream>>>(ds, pb, ps, b, max_depth, gs);
+  if (bins_present & 2u) shade_kernel<1, STATS, SOLID><<<grid, kBlock, 0, stream>>>(ds, pb, ps, b, max_depth, gs);
+  if (bins_present & 4u) shade_kernel<2, STATS, SOLID><<<grid, kBlock, 0, stream>>>(ds, pb, ps, b, max_depth, gs);
+  if (bins_present & 8u) shade_kernel<3, STATS, SOLID><<<grid, kBlock, 0, stream>>>(ds, pb, ps, b, max_depth, gs);
+  if (bins_present & 16u) shade_kernel<4, STATS, SOLID><<<grid, kBlock, 0, stream>>>(ds, pb, ps, b, max_depth, gs);
+  if (bins_present & 32u) shade_kernel<5, STATS, SOLID><<<grid, kBlock, 0, stream>>>(ds, pb, ps, b, max_depth, gs);
 }
 
 // -------------------------------------------------------------- resolve
@@ -593,6 +609,10 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats) {
   if (const char* e = getenv("MI355RT_BLOCKS_PER_CU")) blocks_per_cu = (uint32_t)strtoul(e, nullptr, 10);
   const uint32_t max_grid = ctx->n_cus * std::max(1u, blocks_per_cu);
   const bool media = ctx->flat.has_media;
+  bool solid = true;
+  for (const DTexture& t : ctx->flat.textures) solid = solid && t.kind == RT_TEX_SOLID;
+  uint32_t bins_present = 1u;
+  for (const DMaterial& m : ctx->flat.materials) bins_present |= 2u << m.kind;
   const LdsLayout lds = ctx->lds;
 
   for (uint32_t done = 0; done < n_samples; done += per_pass) {
@@ -612,12 +632,14 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats) {
         if (media) extend_kernel<true, true><<<grid, kBlock, lds.bytes, ctx->stream>>>(ctx->ds, lds, pb, ps, b, gs);
         else extend_kernel<true, false><<<grid, kBlock, lds.bytes, ctx->stream>>>(ctx->ds, lds, pb, ps, b, gs);
         if (want_timing) RT_HIP(ctx, stamp());
-        shade_kernel<true><<<grid, kBlock, 0, ctx->stream>>>(ctx->ds, pb, ps, b, p->max_depth, gs);
+        if (solid) launch_shade<true, true>(bins_present, grid, ctx->stream, ctx->ds, pb, ps, b, p->max_depth, gs);
+        else launch_shade<true, false>(bins_present, grid, ctx->stream, ctx->ds, pb, ps, b, p->max_depth, gs);
       } else {
         if (media) extend_kernel<false, true><<<grid, kBlock, lds.bytes, ctx->stream>>>(ctx->ds, lds, pb, ps, b, gs);
         else extend_kernel<false, false><<<grid, kBlock, lds.bytes, ctx->stream>>>(ctx->ds, lds, pb, ps, b, gs);
         if (want_timing) RT_HIP(ctx, stamp());
-        shade_kernel<false><<<grid, kBlock, 0, ctx->stream>>>(ctx->ds, pb, ps, b, p->max_depth, gs);
+        if (solid) launch_shade<false, true>(bins_present, grid, ctx->stream, ctx->ds, pb, ps, b, p->max_depth, gs);
+        else launch_shade<false, false>(bins_present, grid, ctx->stream, ctx->ds, pb, ps, b, p->max_depth, gs);
       }
       if (want_timing) RT_HIP(ctx, stamp());
       // every 8 bounces look at the live count: stop when no path is left and

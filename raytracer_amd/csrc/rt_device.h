@@ -306,8 +306,10 @@ RT_DEV void sphere_uv(V3 n, double& u, double& v) {  // Sphere::get_uv, sphere.r
 
 // The HitRecord the reference would return for leaf slot `pr` hit at parameter t
 // by the world-frame ray (o, d, time).
+template <bool UV_POSSIBLE = true>
 RT_DEV Record make_record(const DeviceScene& sc, const DPrim& pr, V3 o, V3 d, double time, double t,
                           bool want_uv) {
+  if (!UV_POSSIBLE) want_uv = false;  // no texture of the scene reads (u, v): drops acos/atan2
   Record r;
   r.u = 0.0;
   r.v = 0.0;
@@ -563,9 +565,10 @@ RT_DEV uint32_t as_u32_sat(double x) {
   return (uint32_t)x;
 }
 
-template <bool STATS>
+template <bool STATS, bool SOLID_ONLY = false>
 RT_DEV V3 texture_value(const DeviceScene& sc, uint32_t tex, double u, double v, V3 p, Stats& st) {
   DTexture t = sc.textures[tex];
+  if (SOLID_ONLY) return v3(t.color);  // every texture of the scene is a SolidColor
   // Checkerboard::value (checkerboard.rs:17-28); children have lower indices, so this ends
   while (t.kind == RT_TEX_CHECKER) {
     stat<STATS>(st, RT_STAT_TEX_CHECKER);
