@@ -311,10 +311,12 @@ int rt_first_hit(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_window* 
 
 /* The flattened acceleration structure the device walks, for inspection and
  * for instrumented CPU traversal.  nodes: 32-byte records
- * {float lo[3]; float hi[3]; uint32 a; uint32 b} (interior: a=left child,
- * right=a+1, b=0x80000000|split axis; leaf: a=first item, b=item count).  items: for each leaf slot
- * the index of the top-level object and the primitive inside it (or
- * 0xFFFFFFFF when the slot is the whole object: a constant medium). */
+ * {float lo[3]; float hi[3]; uint32 a; uint32 b}, record 0 is the root.
+ * Interior: a = first child, b = 0x80000000 | (children - 1) with 2..4 children
+ * stored consecutively at a..; leaf: a = first item, b = item count (1..8).
+ * Records are numbered breadth-first.  items: for each leaf slot the index of
+ * the top-level object and the primitive inside it (or 0xFFFFFFFF when the slot
+ * is the whole object: a constant medium). */
 typedef struct rt_bvh_node {
   float lo[3];
   float hi[3];

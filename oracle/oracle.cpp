@@ -1046,11 +1046,13 @@ struct FlatBvh {
   uint32_t n_nodes = 0, n_items = 0;
 };
 
-// Closest hit over the flattened BVH, walked the way the device walks it: fetch a
-// node, slab-test its own float box against [t_start, best t], a leaf tests its
-// items, an interior node pushes the far child (by the sign of the ray direction
-// on the node's split axis) and descends into the near one.  Ties on t resolve
-// to the lower rank.
+// Closest hit over the flattened (up to four-wide) BVH, walked the way the device
+// walks it: a visit of an interior record slab-tests its consecutive children in
+// f32 against [t_start, best t], goes on with the hit child that is entered
+// first (strictly: the earlier child keeps a tie) and stacks the other hit
+// children with their entry parameter; a popped entry whose entry parameter lies
+// beyond the best t by now is dropped.  The root's own box is not tested.  Ties
+// on t resolve to the lower rank.
 OptHit flat_hit(const SceneData& sc, const FlatBvh& bvh, const Ray& ray, Range t_range,
                 const HitCtx& cx) {
   OptHit best;
@@ -1071,30 +1073,76 @@ OptHit flat_hit(const SceneData& sc, const FlatBvh& bvh, const Ray& ray, Range t
   }
   const float tmin32 = (float)t_range.start * 0.99f;
   const float widen = 1.000003814697265625f;  // 1 + 2^-18
-  float best32 = std::numeric_limits<float>::infinity();
-  uint32_t stack[64];
-  int sp = 0;
-  uint32_t node = 0;
-  for (;;) {
-    const rt_bvh_node& n = bvh.nodes[node];
-    if (cx.count) cx.count->v[RT_STAT_BOX_TESTS]++;
-    float near[3], far[3];
-    for (int a = 0; a < 3; ++a) {
-      float ta = std::fmaf(n.lo[a], inv[a], noi_lo[a]);
-      float tb = std::fmaf(n.hi[a], inv[a], noi_hi[a]);
-      near[a] = std::fmin(ta, tb);
-      far[a] = std::fmax(ta, tb);
-    }
-    float t0 = std::fmax(std::fmax(near[0], near[1]), std::fmax(near[2], tmin32));
-    float t1 = std::fmin(std::fmin(far[0], far[1]), std::fmin(far[2], best32));
-    if (t0 <= t1 * widen) {
-      if (n.b & 0x80000000u) {
-        uint32_t axis = n.b & 3u;
-        uint32_t neg = ray.direction[(int)axis] < 0.0 ? 1u : 0u;
-        if (sp < 64) stack[sp++] = n.a + 1u - neg;
-        node = n.a + neg;
-        continue;
+  const float finf = std::numeric_limits<float>::infinity();
+  float best32 = finf;
+  // a stack word keeps only the leading bits of the entry parameter that fit beside the
+  // entry code: the low (ebits - 1) float bits are cleared (rounds down)
+  uint32_t ebits;
+  {
+    uint32_t hi = (bvh.n_nodes << 3) > (bvh.n_items << 4) ? (bvh.n_nodes << 3) : (bvh.n_items << 4);
+    ebits = 1;
+    while (ebits < 31 && (hi >> ebits) != 0) ++ebits;
+  }
+  auto truncated = [&](float t) {
+    uint32_t u;
+    std::memcpy(&u, &t, 4);
+    u = (u >> (ebits - 1u)) << (ebits - 1u);
+    std::memcpy(&t, &u, 4);
+    return t;
+  };
+  struct Entry {
+    uint32_t node;  // record index
+    float t;
+  };
+  std::vector<Entry> stack;
+  auto pop = [&](uint32_t& out) -> bool {
+    while (!stack.empty()) {
+      Entry e = stack.back();
+      stack.pop_back();
+      if (e.t <= best32 * widen) {
+        out = e.node;
+        return true;
       }
+    }
+    return false;
+  };
+  uint32_t cur = 0;
+  for (;;) {
+    const rt_bvh_node& n = bvh.nodes[cur];
+    bool have_next = false;
+    uint32_t next = 0;
+    if (n.b & 0x80000000u) {
+      uint32_t kids = (n.b & 3u) + 1u;
+      float near_t = finf;
+      bool have_near = false;
+      uint32_t near = 0;
+      for (uint32_t k = 0; k < kids; ++k) {
+        const rt_bvh_node& c = bvh.nodes[n.a + k];
+        if (cx.count) cx.count->v[RT_STAT_BOX_TESTS]++;
+        float lo3[3], hi3[3];
+        for (int a = 0; a < 3; ++a) {
+          float ta = std::fmaf(c.lo[a], inv[a], noi_lo[a]);
+          float tb = std::fmaf(c.hi[a], inv[a], noi_hi[a]);
+          lo3[a] = std::fmin(ta, tb);
+          hi3[a] = std::fmax(ta, tb);
+        }
+        float t0 = std::fmax(std::fmax(lo3[0], lo3[1]), std::fmax(lo3[2], tmin32));
+        float t1 = std::fmin(std::fmin(hi3[0], hi3[1]), std::fmin(hi3[2], best32));
+        if (!(t0 <= t1 * widen)) continue;
+        if (t0 < near_t) {
+          if (have_near) stack.push_back(Entry{near, truncated(near_t)});
+          near = n.a + k;
+          near_t = t0;
+          have_near = true;
+        } else {
+          stack.push_back(Entry{n.a + k, truncated(t0)});
+        }
+      }
+      if (have_near) {
+        next = near;
+        have_next = true;
+      }
+    } else {
       for (uint32_t k = 0; k < n.b; ++k) {
         const rt_bvh_item& it = bvh.items[n.a + k];
         const Hittable* h = it.prim == 0xFFFFFFFFu ? sc.object_items[it.object].get()
@@ -1110,8 +1158,8 @@ OptHit flat_hit(const SceneData& sc, const FlatBvh& bvh, const Ray& ray, Range t
         }
       }
     }
-    if (sp == 0) break;
-    node = stack[--sp];
+    if (!have_next && !pop(next)) break;
+    cur = next;
   }
   return best;
 }

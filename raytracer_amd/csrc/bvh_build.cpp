@@ -238,14 +238,22 @@ struct BuildItem {
   uint32_t slot;  // index into the pre-order item list
 };
 
+// Node of the binary SAH tree the wide hierarchy is collapsed from.
+struct BinNode {
+  Box box;
+  uint32_t left = 0;   // children left, left + 1 (interior)
+  uint32_t first = 0;  // first leaf slot (leaf)
+  uint32_t count = 0;  // leaf: item count; interior: 0
+};
+
 struct Builder {
   uint32_t max_leaf = 2;
   std::vector<BuildItem>& items;
-  std::vector<rt_bvh_node>& nodes;
+  std::vector<BinNode>& nodes;
   std::vector<uint32_t>& leaf_order;  // slots in leaf order
   uint32_t max_depth = 0;
 
-  Builder(std::vector<BuildItem>& i, std::vector<rt_bvh_node>& n, std::vector<uint32_t>& lo)
+  Builder(std::vector<BuildItem>& i, std::vector<BinNode>& n, std::vector<uint32_t>& lo)
       : items(i), nodes(n), leaf_order(lo) {}
 
   // Can `count` items still be split into leaves within `levels` more interior levels?
@@ -261,11 +269,11 @@ struct Builder {
       bounds.grow(items[i].box);
       cbounds.grow(items[i].centroid);
     }
-    store_box(bounds, nodes[node_index]);
+    nodes[node_index].box = bounds;
     size_t count = end - begin;
     if (count <= max_leaf) {
-      nodes[node_index].a = (uint32_t)leaf_order.size();
-      nodes[node_index].b = (uint32_t)count;
+      nodes[node_index].first = (uint32_t)leaf_order.size();
+      nodes[node_index].count = (uint32_t)count;
       for (size_t i = begin; i < end; ++i) leaf_order.push_back(items[i].slot);
       return;
     }
@@ -348,12 +356,73 @@ struct Builder {
     uint32_t left = (uint32_t)nodes.size();
     nodes.emplace_back();
     nodes.emplace_back();
-    nodes[node_index].a = left;
-    nodes[node_index].b = 0x80000000u | (uint32_t)axis;
+    nodes[node_index].left = left;
+    nodes[node_index].count = 0;
     build(left, begin, mid, depth + 1);
     build(left + 1, mid, end, depth + 1);
   }
 };
+
+// Collapse the binary tree into nodes of up to four children.  Output records are
+// numbered breadth-first and the children of a node are consecutive, so one visit
+// reads up to 128 contiguous bytes and the head of the array is the top of the tree.
+// Returns the number of stack entries a traversal can need: a visit pushes at most
+// (children - 1) entries before descending.
+uint32_t collapse_wide(const std::vector<BinNode>& bin, std::vector<rt_bvh_node>& out,
+                       uint32_t& depth_out) {
+  out.clear();
+  out.emplace_back();
+  store_box(bin[0].box, out[0]);
+  struct Pending {
+    uint32_t bin_index, record, depth;
+  };
+  std::vector<Pending> queue{{0u, 0u, 0u}};
+  std::vector<uint32_t> need;  // per record: stack entries its subtree can need (filled backwards)
+  depth_out = 0;
+  for (size_t q = 0; q < queue.size(); ++q) {
+    Pending cur = queue[q];
+    depth_out = std::max(depth_out, cur.depth);
+    const BinNode& n = bin[cur.bin_index];
+    if (n.count) {
+      out[cur.record].a = n.first;
+      out[cur.record].b = n.count;
+      continue;
+    }
+    // expand the interior child with the largest box until there are four
+    uint32_t kids[4] = {n.left, n.left + 1, 0, 0};
+    uint32_t k = 2;
+    while (k < 4) {
+      int pick = -1;
+      double area = -1.0;
+      for (uint32_t i = 0; i < k; ++i)
+        if (bin[kids[i]].count == 0 && bin[kids[i]].box.area() > area) {
+          area = bin[kids[i]].box.area();
+          pick = (int)i;
+        }
+      if (pick < 0) break;
+      uint32_t expanded = kids[pick];
+      kids[pick] = bin[expanded].left;
+      kids[k++] = bin[expanded].left + 1;
+    }
+    uint32_t first = (uint32_t)out.size();
+    out[cur.record].a = first;
+    out[cur.record].b = 0x80000000u | (k - 1u);
+    for (uint32_t i = 0; i < k; ++i) {
+      out.emplace_back();
+      store_box(bin[kids[i]].box, out.back());
+      queue.push_back({kids[i], first + i, cur.depth + 1});
+    }
+  }
+  // children have larger indices than their parent: one backward sweep settles `need`
+  need.assign(out.size(), 0);
+  for (size_t i = out.size(); i-- > 0;) {
+    if (!(out[i].b & 0x80000000u)) continue;
+    uint32_t k = (out[i].b & 3u) + 1u, deepest = 0;
+    for (uint32_t c = 0; c < k; ++c) deepest = std::max(deepest, need[out[i].a + c]);
+    need[i] = (k - 1u) + deepest;
+  }
+  return std::max(1u, need[0]);
+}
 
 uint32_t pack_ops(uint32_t first, uint32_t count) { return (first & 0x00FFFFFFu) | (count << 24); }
 
@@ -524,32 +593,18 @@ std::string flatten_scene(const rt_scene& s, FlatScene& out, int& code) {
     }
 
   if (!build_items.empty()) {
-    out.nodes.reserve(build_items.size() * 2);
-    out.nodes.emplace_back();
+    std::vector<BinNode> bin;
+    bin.reserve(build_items.size() * 2);
+    bin.emplace_back();
     std::vector<uint32_t> leaf_order;
     leaf_order.reserve(build_items.size());
-    Builder b(build_items, out.nodes, leaf_order);
+    Builder b(build_items, bin, leaf_order);
     if (const char* e = getenv("MI355RT_LEAF_ITEMS")) {
       unsigned long v = strtoul(e, nullptr, 10);
       if (v >= 1 && v <= kMaxLeafItems) b.max_leaf = (uint32_t)v;
     }
     b.build(0, 0, build_items.size(), 0);
-    out.bvh_depth = b.max_depth;
-    // Renumber breadth-first: the top of the tree becomes the head of the array,
-    // which is the part the kernels keep in LDS.  Sibling pairs stay adjacent.
-    {
-      std::vector<rt_bvh_node> bfs;
-      bfs.reserve(out.nodes.size());
-      bfs.push_back(out.nodes[0]);
-      for (size_t i = 0; i < bfs.size(); ++i) {
-        if (!(bfs[i].b & 0x80000000u)) continue;
-        uint32_t old_left = bfs[i].a;
-        bfs[i].a = (uint32_t)bfs.size();
-        bfs.push_back(out.nodes[old_left]);
-        bfs.push_back(out.nodes[old_left + 1]);
-      }
-      out.nodes.swap(bfs);
-    }
+    out.stack_entries = collapse_wide(bin, out.nodes, out.bvh_depth);
     out.prims.reserve(leaf_order.size());
     for (uint32_t slot : leaf_order) {
       out.prims.push_back(slots[slot]);
@@ -557,9 +612,13 @@ std::string flatten_scene(const rt_scene& s, FlatScene& out, int& code) {
       out.ranks.push_back(slot_items[slot].rank);
     }
   }
-  if (out.bvh_depth > kMaxBvhDepth) {
+  if (out.items.size() >= (1u << 26) || out.nodes.size() >= (1u << 27)) {
     code = RT_ERR_LIMIT;
-    return "acceleration structure deeper than the traversal stack";
+    return "acceleration structure too large for the packed traversal entries";
+  }
+  if (out.stack_entries > kMaxStackEntries) {
+    code = RT_ERR_LIMIT;
+    return "acceleration structure needs a deeper traversal stack than LDS holds";
   }
   code = RT_OK;
   return "";

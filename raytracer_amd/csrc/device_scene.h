@@ -71,7 +71,8 @@ struct DImage {  // 16 bytes
   uint64_t offset;
 };
 
-const uint32_t kMaxBvhDepth = 32;   // interior levels; bounds the traversal stack
+const uint32_t kMaxBvhDepth = 32;      // levels of the binary tree the wide one is collapsed from
+const uint32_t kMaxStackEntries = 64;  // 8-byte traversal stack entries per lane that LDS can hold
 const uint32_t kMaxLeafItems = 8;     // upper bound; the builder's default is lower
 const uint32_t kNoPrim = 0xFFFFFFFFu;
 
@@ -91,7 +92,8 @@ struct FlatScene {
   std::vector<uint8_t> texels;
   rt_camera camera{};
   double background[3] = {0, 0, 0};
-  uint32_t bvh_depth = 0;
+  uint32_t bvh_depth = 0;      // levels of the wide hierarchy
+  uint32_t stack_entries = 1;  // traversal stack entries a ray can need
   bool has_media = false;
 };
 

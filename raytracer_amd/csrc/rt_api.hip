@@ -64,7 +64,7 @@ RT_DEV uint32_t lane_id() { return __lane_id(); }
 // bin, so a workgroup collects entries in an LDS buffer (slots handed out by an
 // LDS atomic per wave: ballot + popcount) and moves them to the global queue in
 // runs of kFlushAt or more, with ONE global atomic per run and coalesced stores.
-const uint32_t kFlushAt = 512;               // flush a staged queue at this many entries
+const uint32_t kFlushAt = 256;               // flush a staged queue at this many entries
 const uint32_t kStageCap = kFlushAt + kBlock;  // a round adds at most kBlock entries
 
 // Slot in the LDS stage for each active lane.  Must be reached by whole waves.
@@ -744,17 +744,21 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* scene) {
   ds.texels = ctx->texels.p;
   ds.n_nodes = (uint32_t)f.nodes.size();
   ds.has_media = f.has_media ? 1u : 0u;
+  ds.root_a = f.nodes.empty() ? 0u : f.nodes[0].a;
+  ds.root_b = f.nodes.empty() ? 1u : f.nodes[0].b;
   ds.cam = f.camera;
   std::memcpy(ds.bg, f.background, sizeof ds.bg);
   // LDS plan per 256-thread workgroup: the traversal stack (one entry per BVH level),
   // then as many top-of-tree nodes as fit, then leaf slots with what is left.
   {
-    uint32_t budget = 20u * 1024u;
+    uint32_t budget = 27u * 1024u;  // with the kernels' 12.3 KB of staged queues: 4 workgroups per CU
     if (const char* e = getenv("MI355RT_LDS_BYTES")) budget = (uint32_t)strtoul(e, nullptr, 10);
     budget = std::min(budget, 160u * 1024u);
     LdsLayout& l = ctx->lds;
-    l.stack_depth = std::max(1u, f.bvh_depth);
+    l.stack_depth = std::max(1u, f.stack_entries);
+    l.entry_bits = entry_code_bits((uint32_t)f.nodes.size(), (uint32_t)f.items.size());
     uint32_t used = l.stack_depth * kBlock * (uint32_t)sizeof(uint32_t);
+    budget = std::max(budget, used + 4096u);  // the stack is not optional; leave room for a few nodes
     uint32_t room = budget > used ? budget - used : 0u;
     l.n_nodes = std::min<uint32_t>((uint32_t)f.nodes.size(), room / 32u);
     room -= l.n_nodes * 32u;

@@ -30,6 +30,7 @@ struct DeviceScene {
   const uint8_t* texels;
   uint32_t n_nodes;
   uint32_t has_media;
+  uint32_t root_a, root_b;  // the root record's (a, b)
   rt_camera cam;
   double bg[3];
 };
@@ -200,11 +201,12 @@ RT_DEV V3 moving_center(const DeviceScene& sc, const DPrim& pr, double time) {  
 RT_DEV bool in_range(double t, double lo, double hi) { return lo <= t && t < hi; }  // Range::contains
 
 // Sphere::hit up to the root (sphere.rs:32-51).
+// `a` is ray.direction.length_squared(): the same value for every sphere a ray meets,
+// so callers compute it once per ray (or once per wrapper frame).
 template <bool STATS>
-RT_DEV bool sphere_t(V3 c, double radius, V3 o, V3 d, double tmin, double tmax, double& t,
-                     Stats& st) {
+RT_DEV bool sphere_t(V3 c, double radius, V3 o, V3 d, double a, double tmin, double tmax,
+                     double& t, Stats& st) {
   V3 oc = vsub(o, c);
-  double a = vlen2(d);
   double half_b = vdot(oc, d);
   double cc = vlen2(oc) - radius * radius;
   double discrim = half_b * half_b - a * cc;
@@ -236,19 +238,23 @@ RT_DEV bool rect_t(const DPrim& pr, V3 o, V3 d, double tmin, double tmax, double
 
 // hit().t of one base primitive inside its wrappers, for a ray given in the frame
 // outside those wrappers.
+// `dd` = d.d of the ray as given (used as is when the primitive has no wrappers).
 template <bool STATS>
-RT_DEV bool base_prim_t(const DeviceScene& sc, const DPrim& pr, V3 o, V3 d, double time,
+RT_DEV bool base_prim_t(const DeviceScene& sc, const DPrim& pr, V3 o, V3 d, double dd, double time,
                         double tmin, double tmax, double& t, Stats& st) {
   uint32_t n_ops = ops_count(pr.ops);
-  if (n_ops) ops_forward<STATS>(sc, pr.ops, n_ops, o, d, st);
+  if (n_ops) {
+    ops_forward<STATS>(sc, pr.ops, n_ops, o, d, st);
+    dd = vlen2(d);  // a RotateY in the chain changes the components (not the length, up to rounding)
+  }
   uint32_t kind = pr.kind & 15u;
   if (kind == DP_SPHERE) {
     stat<STATS>(st, RT_STAT_SPHERE_TESTS);
-    return sphere_t<STATS>(v3(pr.p[0], pr.p[1], pr.p[2]), pr.p[3], o, d, tmin, tmax, t, st);
+    return sphere_t<STATS>(v3(pr.p[0], pr.p[1], pr.p[2]), pr.p[3], o, d, dd, tmin, tmax, t, st);
   }
   if (kind == DP_MOVING_SPHERE) {
     stat<STATS>(st, RT_STAT_MSPHERE_TESTS);
-    return sphere_t<STATS>(moving_center(sc, pr, time), pr.p[3], o, d, tmin, tmax, t, st);
+    return sphere_t<STATS>(moving_center(sc, pr, time), pr.p[3], o, d, dd, tmin, tmax, t, st);
   }
   stat<STATS>(st, RT_STAT_RECT_TESTS);
   return rect_t(pr, o, d, tmin, tmax, t);
@@ -263,7 +269,7 @@ RT_DEV bool boundary_t(const DeviceScene& sc, uint32_t first, uint32_t count, V3
   for (uint32_t k = 0; k < count; ++k) {
     const DPrim pr = sc.boundary[first + k];
     double tk;
-    if (base_prim_t<STATS>(sc, pr, o, d, time, tmin, tmax, tk, st)) {
+    if (base_prim_t<STATS>(sc, pr, o, d, vlen2(d), time, tmin, tmax, tk, st)) {
       if (!any || tk < t) t = tk;
       any = true;
     }
@@ -390,12 +396,13 @@ struct LdsLayout {
   uint32_t n_prims;      // leaf slots [0, n_prims) are in LDS
   uint32_t stack_depth;  // stack entries per lane
   uint32_t bytes;        // total dynamic LDS bytes per workgroup
+  uint32_t entry_bits;   // bits of a traversal entry code (see entry_code_bits)
 };
 struct LdsScene {
   const float4* nodes;
   const float4* prims;  // 4 x float4 per DPrim
-  uint32_t* stack;      // this lane's column, entries `stack_stride` words apart
-  uint32_t n_nodes, n_prims, stack_stride;
+  uint32_t* stack;      // this lane's column of packed entries, `stack_stride` words apart
+  uint32_t n_nodes, n_prims, stack_stride, entry_bits;
 };
 
 // Carve the workgroup's dynamic LDS and stage the scene head into it.  Every
@@ -416,6 +423,7 @@ RT_DEV LdsScene lds_stage(const DeviceScene& sc, const LdsLayout& lay, char* sme
   l.n_nodes = lay.n_nodes;
   l.n_prims = lay.n_prims;
   l.stack_stride = block;
+  l.entry_bits = lay.entry_bits;
   return l;
 }
 
@@ -435,15 +443,49 @@ RT_DEV DPrim load_prim(const DeviceScene& sc, const LdsScene& lds, uint32_t slot
   return u.p;
 }
 
-// world.hit(ray, tmin..inf): closest t over the flattened BVH.  Each visited node
-// is slab-tested against [tmin, best t]; an interior node pushes its far child
-// (by direction sign on the split axis) and continues with the near one.  Equal
-// t resolves to the lower rank.
+// world.hit(ray, tmin..inf): closest t over the flattened BVH.
+//
+// A traversal entry is a code for what a record's (a, b) say:
+//   interior: ((first child << 2) | (children - 1)) << 1;  leaf: (((first item << 3) | (count - 1)) << 1) | 1.
+// A visit of an interior entry reads its (up to four, consecutive) child records,
+// slab-tests each against [tmin, best t], continues with the hit child that is
+// entered first and pushes the other hit children together with their entry
+// parameter; a popped entry whose entry parameter now lies beyond the best t is
+// dropped.  A stack word holds the code in its low `entry_bits` bits and, above
+// them, as many leading bits of the (positive) f32 entry parameter as fit:
+// truncation rounds the parameter down, which only makes the drop test keep more.
+// Primitive tests always use the reference's full range tmin..inf so that equal
+// t can be resolved by rank.
+const uint32_t kNoEntry = 0xFFFFFFFFu;
+const float kWiden = 1.000003814697265625f;  // 1 + 2^-18, see cull_axis
+
+RT_HD uint32_t make_entry(uint32_t a, uint32_t b) {
+  return (b & 0x80000000u) ? (((a << 2) | (b & 3u)) << 1) : ((((a << 3) | (b - 1u)) << 1) | 1u);
+}
+// Bits needed for every entry code of a hierarchy with this many records and items.
+RT_HD uint32_t entry_code_bits(uint32_t n_nodes, uint32_t n_items) {
+  uint32_t hi = (n_nodes << 3) > (n_items << 4) ? (n_nodes << 3) : (n_items << 4);
+  uint32_t bits = 1;
+  while (bits < 31 && (hi >> bits) != 0) ++bits;
+  return bits;
+}
+// The entry parameter as a stack word keeps it: low (bits - 1) float bits cleared.
+RT_HD uint32_t stack_t_bits(float t, uint32_t bits) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t u = __float_as_uint(t);
+#else
+  uint32_t u;
+  __builtin_memcpy(&u, &t, 4);
+#endif
+  return (u >> (bits - 1u)) << (bits - 1u);
+}
+
 template <bool STATS, bool MEDIA>
 RT_DEV Closest closest_hit(const DeviceScene& sc, const LdsScene& lds, V3 o, V3 d, double time,
                            double tmin, const DrawKey& key, Stats& st) {
   uint32_t* stack = lds.stack;
   const uint32_t stride = lds.stack_stride;
+  const uint32_t ebits = lds.entry_bits, emask = (1u << ebits) - 1u;
   const double inf = __longlong_as_double(0x7FF0000000000000ll);
   Closest best;
   best.t = inf;
@@ -453,46 +495,69 @@ RT_DEV Closest closest_hit(const DeviceScene& sc, const LdsScene& lds, V3 o, V3 
   // culling arithmetic: once per ray, then one FMA per slab plane
   const CullAxis cx = cull_axis(o.x, d.x), cy = cull_axis(o.y, d.y), cz = cull_axis(o.z, d.z);
   const float tmin32 = (float)tmin * 0.99f;
-  const float kWiden = 1.000003814697265625f;  // 1 + 2^-18
   float best32 = __int_as_float(0x7F800000);
+  const double dd = vlen2(d);
   uint32_t sp = 0;
-  uint32_t node = 0;
-  const uint32_t kNone = 0xFFFFFFFFu;
-  while (node != kNone) {
-    // walk down until a leaf passes its box test
-    uint32_t leaf_first = 0, leaf_count = 0;
-    while (node != kNone) {
-      float4 n0, n1;
-      if (node < lds.n_nodes) {
-        n0 = lds.nodes[2 * node];
-        n1 = lds.nodes[2 * node + 1];
-      } else {
-        n0 = sc.nodes[2 * node];
-        n1 = sc.nodes[2 * node + 1];
-      }
-      stat<STATS>(st, RT_STAT_BOX_TESTS);
-      float ax = fmaf(n0.x, cx.inv, cx.noi_lo), bx = fmaf(n0.w, cx.inv, cx.noi_hi);
-      float ay = fmaf(n0.y, cy.inv, cy.noi_lo), by = fmaf(n1.x, cy.inv, cy.noi_hi);
-      float az = fmaf(n0.z, cz.inv, cz.noi_lo), bz = fmaf(n1.y, cz.inv, cz.noi_hi);
-      float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin32));
-      float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best32));
-      uint32_t a = __float_as_uint(n1.z), b = __float_as_uint(n1.w);
-      if (t0 <= t1 * kWiden) {
-        if (b & 0x80000000u) {
-          uint32_t axis = b & 3u;
-          uint32_t neg = vget(d, axis) < 0.0 ? 1u : 0u;
-          stack[sp * stride] = a + 1u - neg;
-          ++sp;
-          node = a + neg;
-          continue;
-        }
-        leaf_first = a;
-        leaf_count = b;
-        node = sp ? stack[(--sp) * stride] : kNone;
+  uint32_t cur = make_entry(sc.root_a, sc.root_b);  // the root's own box is not tested
+
+  // next entry from the stack that can still matter, or kNoEntry
+  auto pop = [&]() -> uint32_t {
+    while (sp) {
+      uint32_t w = stack[(--sp) * stride];
+      if (__uint_as_float((w >> ebits) << (ebits - 1u)) <= best32 * kWiden) return w & emask;
+    }
+    return kNoEntry;
+  };
+
+  for (;;) {
+    // descend until the current entry is a leaf
+    uint32_t leaf = kNoEntry;
+    while (cur != kNoEntry) {
+      if (cur & 1u) {
+        leaf = cur;
         break;
       }
-      node = sp ? stack[(--sp) * stride] : kNone;
+      const uint32_t first = cur >> 3, n = ((cur >> 1) & 3u) + 1u;
+      const bool in_lds = first + 4u <= lds.n_nodes;
+      uint32_t near_entry = kNoEntry;
+      float near_t = __int_as_float(0x7F800000);
+#pragma unroll
+      for (uint32_t k = 0; k < 4; ++k) {
+        if (k < n) {
+          float4 n0, n1;
+          if (in_lds) {
+            n0 = lds.nodes[2 * (first + k)];
+            n1 = lds.nodes[2 * (first + k) + 1];
+          } else {
+            n0 = sc.nodes[2 * (first + k)];
+            n1 = sc.nodes[2 * (first + k) + 1];
+          }
+          stat<STATS>(st, RT_STAT_BOX_TESTS);
+          float ax = fmaf(n0.x, cx.inv, cx.noi_lo), bx = fmaf(n0.w, cx.inv, cx.noi_hi);
+          float ay = fmaf(n0.y, cy.inv, cy.noi_lo), by = fmaf(n1.x, cy.inv, cy.noi_hi);
+          float az = fmaf(n0.z, cz.inv, cz.noi_lo), bz = fmaf(n1.y, cz.inv, cz.noi_hi);
+          float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin32));
+          float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best32));
+          if (t0 <= t1 * kWiden) {
+            uint32_t e = make_entry(__float_as_uint(n1.z), __float_as_uint(n1.w));
+            if (t0 < near_t) {  // strict: the earlier child keeps a tie
+              if (near_entry != kNoEntry) {
+                stack[sp * stride] = ((__float_as_uint(near_t) >> (ebits - 1u)) << ebits) | near_entry;
+                ++sp;
+              }
+              near_entry = e;
+              near_t = t0;
+            } else {
+              stack[sp * stride] = ((__float_as_uint(t0) >> (ebits - 1u)) << ebits) | e;
+              ++sp;
+            }
+          }
+        }
+      }
+      cur = near_entry != kNoEntry ? near_entry : pop();
     }
+    if (leaf == kNoEntry) break;
+    const uint32_t leaf_first = leaf >> 4, leaf_count = ((leaf >> 1) & 7u) + 1u;
     for (uint32_t k = 0; k < leaf_count; ++k) {
       uint32_t slot = leaf_first + k;
       const DPrim pr = load_prim(sc, lds, slot);
@@ -503,7 +568,7 @@ RT_DEV Closest closest_hit(const DeviceScene& sc, const LdsScene& lds, V3 o, V3 
       else if (!MEDIA && (pr.kind & 15u) == DP_MEDIUM)
         hit = false;
       else
-        hit = base_prim_t<STATS>(sc, pr, o, d, time, tmin, inf, t, st);
+        hit = base_prim_t<STATS>(sc, pr, o, d, dd, time, tmin, inf, t, st);
       if (hit) {
         if (t < best.t || (t == best.t && best.item != kNoPrim &&
                            sc.ranks[slot] < sc.ranks[best.item])) {
@@ -514,6 +579,7 @@ RT_DEV Closest closest_hit(const DeviceScene& sc, const LdsScene& lds, V3 o, V3 
         }
       }
     }
+    cur = pop();  // after the leaf: its hits may already rule the next entries out
   }
   return best;
 }

@@ -85,7 +85,8 @@ def test_bvh_invariants(golden_dir, name):
         o = v.objects[int(it["object"])]
         k = 0 if it["prim"] == 0xFFFFFFFF else int(it["prim"]) - o.first_prim
         assert int(it["rank"]) == base[int(it["object"])] + k
-    # children lie inside their parent, sibling pairs are adjacent, leaves tile the item array
+    # children lie inside their parent and are consecutive, numbering is breadth-first,
+    # leaves tile the item array
     seen_items = np.zeros(len(items), dtype=bool)
     stack = [(0, 0)]
     max_seen = 0
@@ -94,8 +95,10 @@ def test_bvh_invariants(golden_dir, name):
         max_seen = max(max_seen, d)
         node = nodes[n]
         if node["b"] & 0x80000000:
-            for c in (int(node["a"]), int(node["a"]) + 1):
-                assert c > n  # breadth-first numbering
+            kids = int(node["b"] & 3) + 1
+            assert 2 <= kids <= 4
+            for c in range(int(node["a"]), int(node["a"]) + kids):
+                assert c > n
                 assert np.all(nodes[c]["lo"] >= node["lo"]) and np.all(nodes[c]["hi"] <= node["hi"])
                 stack.append((c, d + 1))
         else:

@@ -1,0 +1,20 @@
+"""Operation counts per ray for a scene (instrumented kernels)."""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from raytracer_amd import abi
+from raytracer_amd.render import Context, build_bvh
+from raytracer_amd.scene import HostScene
+name = sys.argv[1] if len(sys.argv) > 1 else "book_cover"
+w, h, spp = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+scene = HostScene.load_frozen(os.path.join(ROOT, "tests", "golden", name + ".rtscene"))
+scene.set_image(w, h)
+nodes, items, depth = build_bvh(scene)
+ctx = Context(0); ctx.upload(scene)
+img, st = ctx.render(ctx.params(w, h, 0, spp, scene.max_depth, seed=1), dtype=np.float32, stats=True)
+rays = float(st[0])
+print(name, "nodes", len(nodes), "items", len(items), "depth", depth)
+for i, n in enumerate(abi.STAT_NAMES[:19]):
+    if st[i]:
+        print(f"  {n:18s} {int(st[i]):14d}  per ray {st[i] / rays:8.3f}")
