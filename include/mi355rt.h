@@ -245,6 +245,9 @@ typedef struct rt_window { /* sub-rectangle of the image; w==0 means the whole i
 } rt_window;
 
 #define RT_FLAG_STATS 1u       /* fill the operation counts of the stats array (instrumented kernels) */
+#define RT_FLAG_BINNED 4u      /* always run the extend / bin-by-material / shade kernels; without it,
+                                  scenes with only SolidColor textures use one fused kernel per bounce
+                                  (RT_STAT_EXTEND_NS then covers it and RT_STAT_SHADE_NS is 0) */
 #define RT_FLAG_TIMING 2u      /* fill the RT_STAT_*_NS / *_LAUNCHES slots: device time of the extend
                                   and shade kernels, from events recorded around every launch */
 

@@ -18,6 +18,7 @@ STAT_NAMES = [
 ]
 RT_FLAG_STATS = 1
 RT_FLAG_TIMING = 2
+RT_FLAG_BINNED = 4
 MISS_ID = 0xFFFFFFFF
 
 

@@ -200,6 +200,65 @@ extend_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32
 }
 
 // ---------------------------------------------------------------- shade
+// What one hit contributes, after Material::scatter / Material::emitted of the
+// material kind `kind` (src/material/*.rs, src/texture/isotropic.rs).
+struct ShadeOut {
+  V3 attenuation, direction, emitted, p;
+  bool scattered, emits;
+};
+
+template <bool STATS, bool SOLID>
+RT_DEV ShadeOut shade_hit(const DeviceScene& sc, uint32_t kind, const DPrim& pr, V3 o, V3 d,
+                          double time, double t, const DrawKey& key, Stats& st) {
+  ShadeOut out;
+  out.attenuation = v3(0.0, 0.0, 0.0);
+  out.direction = v3(0.0, 0.0, 0.0);
+  out.emitted = v3(0.0, 0.0, 0.0);
+  out.scattered = false;
+  out.emits = false;
+  stat<STATS>(st, RT_STAT_SHADE_LAMBERTIAN + (int)kind);
+  const DMaterial m = sc.materials[pr.material];
+  const bool textured = kind == RT_MAT_LAMBERTIAN || kind == RT_MAT_DIFFUSE_LIGHT ||
+                        kind == RT_MAT_ISOTROPIC;
+  bool want_uv = textured && ((pr.kind >> 11) & 1u);
+  Record rec = make_record<!SOLID>(sc, pr, o, d, time, t, want_uv);
+  out.p = rec.p;
+  if (kind == RT_MAT_LAMBERTIAN) {  // lambertian.rs:13-25
+    V3 dir = vadd(rec.normal, rand_unit_vector(key));
+    if (vnear_zero(dir)) dir = rec.normal;
+    out.direction = dir;
+    out.attenuation = texture_value<STATS, SOLID>(sc, m.texture, rec.u, rec.v, rec.p, st);
+    out.scattered = true;
+  } else if (kind == RT_MAT_METAL) {  // metal.rs:12-28
+    V3 reflected = vreflect(vunit(d), rec.normal);
+    if (vdot(reflected, rec.normal) > 0.0) {
+      out.direction = vadd(reflected, vscale(rand_unit_vector(key), m.param));
+      out.scattered = true;
+    }
+    out.attenuation = v3(m.albedo);
+  } else if (kind == RT_MAT_DIELECTRIC) {  // dielectric.rs:14-38
+    double ratio = rec.front ? 1.0 / m.param : m.param;
+    V3 ud = vunit(d);
+    double cos_theta = fmin(vdot(vneg(ud), rec.normal), 1.0);
+    double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
+    bool cannot_refract = ratio * sin_theta > 1.0;
+    u32x4 fb = draw(key, DRAW_FRESNEL, 0);
+    bool should_reflect = reflectance(cos_theta, ratio) > u01_53(fb.x, fb.y);
+    out.direction = (cannot_refract || should_reflect) ? vreflect(ud, rec.normal)
+                                                       : vrefract(ud, rec.normal, ratio);
+    out.attenuation = v3(1.0, 1.0, 1.0);
+    out.scattered = true;
+  } else if (kind == RT_MAT_DIFFUSE_LIGHT) {  // emissive.rs:10-12; never scatters
+    out.emitted = texture_value<STATS, SOLID>(sc, m.texture, rec.u, rec.v, rec.p, st);
+    out.emits = true;
+  } else {  // isotropic.rs:10-17
+    out.attenuation = texture_value<STATS, SOLID>(sc, m.texture, rec.u, rec.v, rec.p, st);
+    out.direction = rand_unit_vector(key);
+    out.scattered = true;
+  }
+  return out;
+}
+
 // One instantiation per bin (BIN 0 = misses, BIN 1 + k = material kind k), each
 // launched over its own queue: a kernel carries only its material's code and
 // registers.  SOLID: every texture of the scene is a SolidColor (no texture walk,
@@ -237,64 +296,26 @@ shade_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps, uint32_t bounce, uint3
         V3 add = vmul(beta, v3(sc.bg));
         pb.radiance[path] = make_double4(L.x + add.x, L.y + add.y, L.z + add.z, 0.0);
       } else {
-        const uint32_t kind = (uint32_t)BIN - 1u;
-        stat<STATS>(st, RT_STAT_SHADE_LAMBERTIAN + (int)kind);
         double4 ro = pb.ray_o[path];
         double4 rdv = pb.ray_d[path];
-        V3 o = v3(ro.x, ro.y, ro.z), d = v3(rdv.x, rdv.y, rdv.z);
-        double time = ro.w, t = rdv.w;
         const DPrim pr = sc.prims[pb.hit_item[path]];
-        const DMaterial m = sc.materials[pr.material];
-        const bool textured = kind == RT_MAT_LAMBERTIAN || kind == RT_MAT_DIFFUSE_LIGHT ||
-                              kind == RT_MAT_ISOTROPIC;
-        bool want_uv = textured && ((pr.kind >> 11) & 1u);
-        Record rec = make_record<!SOLID>(sc, pr, o, d, time, t, want_uv);
         uint32_t s_local = path / ps.n_pixels, local = path % ps.n_pixels;
         uint32_t x = ps.x0 + local % ps.ww, y = ps.y0 + local / ps.ww;
         DrawKey key{ps.seed, y * ps.width + x, ps.sample_base + s_local, bounce};
-        V3 attenuation = v3(0.0, 0.0, 0.0), dir = v3(0.0, 0.0, 0.0);
-        bool scattered = false;
-        if (kind == RT_MAT_LAMBERTIAN) {  // lambertian.rs:13-25
-          dir = vadd(rec.normal, rand_unit_vector(key));
-          if (vnear_zero(dir)) dir = rec.normal;
-          attenuation = texture_value<STATS, SOLID>(sc, m.texture, rec.u, rec.v, rec.p, st);
-          scattered = true;
-        } else if (kind == RT_MAT_METAL) {  // metal.rs:12-28
-          V3 reflected = vreflect(vunit(d), rec.normal);
-          if (vdot(reflected, rec.normal) > 0.0) {
-            dir = vadd(reflected, vscale(rand_unit_vector(key), m.param));
-            scattered = true;
-          }
-          attenuation = v3(m.albedo);
-        } else if (kind == RT_MAT_DIELECTRIC) {  // dielectric.rs:14-38
-          double ratio = rec.front ? 1.0 / m.param : m.param;
-          V3 ud = vunit(d);
-          double cos_theta = fmin(vdot(vneg(ud), rec.normal), 1.0);
-          double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
-          bool cannot_refract = ratio * sin_theta > 1.0;
-          u32x4 fb = draw(key, DRAW_FRESNEL, 0);
-          bool should_reflect = reflectance(cos_theta, ratio) > u01_53(fb.x, fb.y);
-          dir = (cannot_refract || should_reflect) ? vreflect(ud, rec.normal)
-                                                   : vrefract(ud, rec.normal, ratio);
-          attenuation = v3(1.0, 1.0, 1.0);
-          scattered = true;
-        } else if (kind == RT_MAT_DIFFUSE_LIGHT) {  // emissive.rs:10-12; never scatters
-          V3 emitted = texture_value<STATS, SOLID>(sc, m.texture, rec.u, rec.v, rec.p, st);
+        ShadeOut so = shade_hit<STATS, SOLID>(sc, (uint32_t)BIN - 1u, pr, v3(ro.x, ro.y, ro.z),
+                                              v3(rdv.x, rdv.y, rdv.z), ro.w, rdv.w, key, st);
+        if (so.emits) {
           double4 L = pb.radiance[path];
-          V3 add = vmul(beta, emitted);
+          V3 add = vmul(beta, so.emitted);
           pb.radiance[path] = make_double4(L.x + add.x, L.y + add.y, L.z + add.z, 0.0);
-        } else {  // isotropic.rs:10-17
-          attenuation = texture_value<STATS, SOLID>(sc, m.texture, rec.u, rec.v, rec.p, st);
-          dir = rand_unit_vector(key);
-          scattered = true;
         }
         // depth budget: the scattered ray of the last allowed hit returns black (main.rs:121-122)
-        if (scattered && bounce + 1u < max_depth) {
+        if (so.scattered && bounce + 1u < max_depth) {
           survives = true;
-          V3 nb = vmul(beta, attenuation);
+          V3 nb = vmul(beta, so.attenuation);
           pb.beta[path] = make_double4(nb.x, nb.y, nb.z, 0.0);
-          pb.ray_o[path] = make_double4(rec.p.x, rec.p.y, rec.p.z, time);
-          pb.ray_d[path] = make_double4(dir.x, dir.y, dir.z, 0.0);
+          pb.ray_o[path] = make_double4(so.p.x, so.p.y, so.p.z, ro.w);
+          pb.ray_d[path] = make_double4(so.direction.x, so.direction.y, so.direction.z, 0.0);
         }
       }
     }
@@ -307,6 +328,93 @@ shade_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps, uint32_t bounce, uint3
     }
   }
   if (BIN != 0 && BIN != 1 + RT_MAT_DIFFUSE_LIGHT) {
+    uint32_t n = s_next_count;
+    if (n) stage_flush(s_next, &s_next_count, &s_word, counters + 6, next_live, n);
+  }
+  if (STATS) flush_stats(st, g_stats);
+}
+
+// ------------------------------------------------------------- trace (fused)
+// Extend and shade in one kernel, for scenes whose shading is cheap (only
+// SolidColor textures): the ray stays in registers between the traversal and the
+// scatter, so the hit record, the bin queues and a second pass over the ray
+// buffers are never written or read.  Material kinds diverge inside a wave here;
+// that costs less than the queue traffic it replaces when shading is a few
+// hundred instructions.  Scenes with procedural or image textures take the
+// binned extend/shade pair above.
+template <bool STATS, bool MEDIA>
+__global__ void __launch_bounds__(kBlock)
+trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_t bounce,
+             uint32_t max_depth, unsigned long long* g_stats) {
+  extern __shared__ __align__(16) char smem[];
+  __shared__ uint32_t s_next[kStageCap];
+  __shared__ uint32_t s_next_count;
+  __shared__ uint32_t s_word;
+  const uint32_t* live = pb.live[bounce & 1u];
+  uint32_t* next_live = pb.live[(bounce + 1u) & 1u];
+  uint32_t* counters = pb.counters + (size_t)bounce * kCounterStride;
+  const uint32_t n_live =
+      bounce == 0 ? ps.n_paths : pb.counters[(size_t)(bounce - 1) * kCounterStride + 6];
+  if (blockIdx.x * kBlock >= n_live) return;
+  if (threadIdx.x == 0) s_next_count = 0;
+  const LdsScene lds = lds_stage(sc, lay, smem, threadIdx.x, kBlock);  // ends with a barrier
+  Stats st;
+  if (STATS) st.clear();
+  const uint32_t stride = gridDim.x * kBlock;
+  for (uint32_t base = blockIdx.x * kBlock; base < n_live; base += stride) {
+    uint32_t i = base + threadIdx.x;
+    bool valid = i < n_live;
+    bool survives = false;
+    uint32_t path = 0;
+    if (valid) {
+      path = bounce == 0 ? i : live[i];
+      double4 ro = pb.ray_o[path];
+      double4 rdv = pb.ray_d[path];
+      V3 o = v3(ro.x, ro.y, ro.z), d = v3(rdv.x, rdv.y, rdv.z);
+      uint32_t s_local = path / ps.n_pixels, local = path % ps.n_pixels;
+      uint32_t x = ps.x0 + local % ps.ww, y = ps.y0 + local / ps.ww;
+      DrawKey key{ps.seed, y * ps.width + x, ps.sample_base + s_local, bounce};
+      stat<STATS>(st, RT_STAT_RAYS);
+      Closest h = closest_hit<STATS, MEDIA>(sc, lds, o, d, ro.w, 0.001, key, st);
+      // the first bounce starts from beta = 1, L = 0 (raygen wrote them; no need to read)
+      V3 beta = v3(1.0, 1.0, 1.0);
+      if (bounce != 0) {
+        double4 bt = pb.beta[path];
+        beta = v3(bt.x, bt.y, bt.z);
+      }
+      if (h.item == kNoPrim) {
+        // miss: the recursion returns `background` (main.rs:137-139)
+        stat<STATS>(st, RT_STAT_SHADE_MISS);
+        V3 add = vmul(beta, v3(sc.bg));
+        double4 L = make_double4(0.0, 0.0, 0.0, 0.0);
+        if (bounce != 0) L = pb.radiance[path];
+        pb.radiance[path] = make_double4(L.x + add.x, L.y + add.y, L.z + add.z, 0.0);
+      } else {
+        stat<STATS>(st, RT_STAT_HITS);
+        const DPrim pr = load_prim(sc, lds, h.item);
+        ShadeOut so = shade_hit<STATS, true>(sc, (h.kind >> 8) & 7u, pr, o, d, ro.w, h.t, key, st);
+        if (so.emits) {
+          double4 L = make_double4(0.0, 0.0, 0.0, 0.0);
+          if (bounce != 0) L = pb.radiance[path];
+          V3 add = vmul(beta, so.emitted);
+          pb.radiance[path] = make_double4(L.x + add.x, L.y + add.y, L.z + add.z, 0.0);
+        }
+        if (so.scattered && bounce + 1u < max_depth) {
+          survives = true;
+          V3 nb = vmul(beta, so.attenuation);
+          pb.beta[path] = make_double4(nb.x, nb.y, nb.z, 0.0);
+          pb.ray_o[path] = make_double4(so.p.x, so.p.y, so.p.z, ro.w);
+          pb.ray_d[path] = make_double4(so.direction.x, so.direction.y, so.direction.z, 0.0);
+        }
+      }
+    }
+    uint32_t slot = stage_append(&s_next_count, survives);
+    if (survives) s_next[slot] = path;
+    __syncthreads();
+    uint32_t n = s_next_count;
+    if (n >= kFlushAt) stage_flush(s_next, &s_next_count, &s_word, counters + 6, next_live, n);
+  }
+  {
     uint32_t n = s_next_count;
     if (n) stage_flush(s_next, &s_next_count, &s_word, counters + 6, next_live, n);
   }
@@ -611,6 +719,9 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats) {
   const bool media = ctx->flat.has_media;
   bool solid = true;
   for (const DTexture& t : ctx->flat.textures) solid = solid && t.kind == RT_TEX_SOLID;
+  // scenes whose shading is cheap run traversal and scatter fused; RT_FLAG_BINNED forces the
+  // extend / shade-per-material pipeline
+  const bool fused = solid && !(p->flags & RT_FLAG_BINNED);
   uint32_t bins_present = 1u;
   for (const DMaterial& m : ctx->flat.materials) bins_present |= 2u << m.kind;
   const LdsLayout lds = ctx->lds;
@@ -628,7 +739,17 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats) {
     for (uint32_t b = 0; b < p->max_depth; ++b) {
       unsigned long long* gs = ctx->stats.p;
       if (want_timing) RT_HIP(ctx, stamp());
-      if (want_stats) {
+      if (fused) {
+        // cheap shading: traversal and scatter in one kernel per bounce
+        if (want_stats) {
+          if (media) trace_kernel<true, true><<<grid, kBlock, lds.bytes, ctx->stream>>>(ctx->ds, lds, pb, ps, b, p->max_depth, gs);
+          else trace_kernel<true, false><<<grid, kBlock, lds.bytes, ctx->stream>>>(ctx->ds, lds, pb, ps, b, p->max_depth, gs);
+        } else {
+          if (media) trace_kernel<false, true><<<grid, kBlock, lds.bytes, ctx->stream>>>(ctx->ds, lds, pb, ps, b, p->max_depth, gs);
+          else trace_kernel<false, false><<<grid, kBlock, lds.bytes, ctx->stream>>>(ctx->ds, lds, pb, ps, b, p->max_depth, gs);
+        }
+        if (want_timing) RT_HIP(ctx, stamp());
+      } else if (want_stats) {
         if (media) extend_kernel<true, true><<<grid, kBlock, lds.bytes, ctx->stream>>>(ctx->ds, lds, pb, ps, b, gs);
         else extend_kernel<true, false><<<grid, kBlock, lds.bytes, ctx->stream>>>(ctx->ds, lds, pb, ps, b, gs);
         if (want_timing) RT_HIP(ctx, stamp());
@@ -766,7 +887,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* scene) {
     if (const char* e = getenv("MI355RT_LDS_PRIMS")) l.n_prims = std::min<uint32_t>(l.n_prims, (uint32_t)strtoul(e, nullptr, 10));
     l.bytes = used + l.n_nodes * 32u + l.n_prims * 64u;
   }
-  if (ctx->lds.bytes > 48u * 1024u) {
+  if (ctx->lds.bytes > 32u * 1024u) {
     int bytes = (int)ctx->lds.bytes;
     const hipFuncAttribute attr = hipFuncAttributeMaxDynamicSharedMemorySize;
     RT_HIP(ctx, hipFuncSetAttribute((const void*)extend_kernel<false, false>, attr, bytes));
@@ -774,6 +895,10 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* scene) {
     RT_HIP(ctx, hipFuncSetAttribute((const void*)extend_kernel<true, false>, attr, bytes));
     RT_HIP(ctx, hipFuncSetAttribute((const void*)extend_kernel<true, true>, attr, bytes));
     RT_HIP(ctx, hipFuncSetAttribute((const void*)first_hit_kernel, attr, bytes));
+    RT_HIP(ctx, hipFuncSetAttribute((const void*)trace_kernel<false, false>, attr, bytes));
+    RT_HIP(ctx, hipFuncSetAttribute((const void*)trace_kernel<false, true>, attr, bytes));
+    RT_HIP(ctx, hipFuncSetAttribute((const void*)trace_kernel<true, false>, attr, bytes));
+    RT_HIP(ctx, hipFuncSetAttribute((const void*)trace_kernel<true, true>, attr, bytes));
   }
   ctx->have_scene = true;
   return RT_OK;

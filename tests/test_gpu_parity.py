@@ -46,13 +46,18 @@ def test_first_hit_matches_golden(gpu_ctx, golden_dir, name):
     assert np.array_equal(n[hit], g["first_normal"][hit])
 
 
+@pytest.mark.parametrize("pipeline", ["default", "binned"])
 @pytest.mark.parametrize("name", SCENES)
-def test_render_window_matches_oracle(gpu_ctx, golden_dir, name):
+def test_render_window_matches_oracle(gpu_ctx, golden_dir, name, pipeline):
+    """default: fused trace kernel for solid-texture scenes; binned: extend + shade per material."""
+    from raytracer_amd import abi
     scene, g = load(golden_dir, name)
     gpu_ctx.upload(scene)
     window = tuple(int(x) for x in g["window"])
     spp, seed, depth = int(g["spp"]), int(g["seed"]), int(g["max_depth"])
-    p = gpu_ctx.params(scene.width, scene.height, 0, spp, depth, seed=seed, window=window)
+    flags = abi.RT_FLAG_BINNED if pipeline == "binned" else 0
+    p = gpu_ctx.params(scene.width, scene.height, 0, spp, depth, seed=seed, window=window,
+                       flags=flags)
     got = gpu_ctx.render(p, dtype=np.float64)
     golden = g["render_sum"]
     scale = np.abs(golden).max()
@@ -96,8 +101,13 @@ def test_stats_match_flat_oracle(gpu_ctx, golden_dir):
     scene, g = load(golden_dir, "book_cover")
     gpu_ctx.upload(scene)
     window = (40, 30, 32, 16)
+    from raytracer_amd import abi
     p = gpu_ctx.params(scene.width, scene.height, 0, 4, 50, seed=9, window=window)
     img, st = gpu_ctx.render(p, dtype=np.float64, stats=True)
+    p2 = gpu_ctx.params(scene.width, scene.height, 0, 4, 50, seed=9, window=window,
+                        flags=abi.RT_FLAG_BINNED)
+    img2, st2 = gpu_ctx.render(p2, dtype=np.float64, stats=True)
+    assert np.array_equal(img, img2) and list(st[:19]) == list(st2[:19])
     nodes, items, _ = build_bvh(scene)
     o = po.Oracle(scene.view_ptr)
     pi = po.make_params(scene.width, scene.height, 0, 4, 50, 9, window=window)
