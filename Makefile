@@ -43,3 +43,9 @@ clean:
 	rm -rf $(LIBDIR) oracle/liboracle.so oracle/_ref
 
 .PHONY: all host device cli oracle clean
+
+# development build with loop-trip counters (tools/lane_profile.py); not shipped
+laneprof:
+	@mkdir -p build/laneprof
+	cp $(LIBDIR)/libmi355rt_host.so build/laneprof/
+	$(HIPCC) $(HIPFLAGS) -DRT_LANE_PROFILE -shared -o build/laneprof/libmi355rt.so $(DEV_SRC)

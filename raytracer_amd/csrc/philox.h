@@ -35,7 +35,10 @@ RT_HD u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1) {
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-  for (int r = 0; r < 10; ++r) {
+#ifndef RT_PHILOX_ROUNDS
+#define RT_PHILOX_ROUNDS 10
+#endif
+  for (int r = 0; r < RT_PHILOX_ROUNDS; ++r) {
     uint32_t hi0 = mulhi32(M0, c.x), lo0 = M0 * c.x;
     uint32_t hi1 = mulhi32(M1, c.z), lo1 = M1 * c.z;
     u32x4 n;

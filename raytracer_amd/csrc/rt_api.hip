@@ -93,10 +93,18 @@ RT_DEV void stage_flush(const uint32_t* lds_buf, uint32_t* lds_count, uint32_t* 
   __syncthreads();
 }
 
+#ifdef RT_LANE_PROFILE
+__device__ unsigned long long g_lane_trips[2 * LP_COUNT];
+#endif
 RT_DEV void flush_stats(const Stats& st, unsigned long long* g) {
 #pragma unroll
   for (int i = 0; i < RT_STAT_COUNT; ++i)
     if (st.v[i]) atomicAdd(g + i, (unsigned long long)st.v[i]);
+#ifdef RT_LANE_PROFILE
+#pragma unroll
+  for (int i = 0; i < 2 * LP_COUNT; ++i)
+    if (st.trips[i]) atomicAdd(g_lane_trips + i, (unsigned long long)st.trips[i]);
+#endif
 }
 
 // --------------------------------------------------------------- raygen
@@ -224,7 +232,7 @@ RT_DEV ShadeOut shade_hit(const DeviceScene& sc, uint32_t kind, const DPrim& pr,
   Record rec = make_record<!SOLID>(sc, pr, o, d, time, t, want_uv);
   out.p = rec.p;
   if (kind == RT_MAT_LAMBERTIAN) {  // lambertian.rs:13-25
-    V3 dir = vadd(rec.normal, rand_unit_vector(key));
+    V3 dir = vadd(rec.normal, rand_unit_vector(key, &st));
     if (vnear_zero(dir)) dir = rec.normal;
     out.direction = dir;
     out.attenuation = texture_value<STATS, SOLID>(sc, m.texture, rec.u, rec.v, rec.p, st);
@@ -232,7 +240,7 @@ RT_DEV ShadeOut shade_hit(const DeviceScene& sc, uint32_t kind, const DPrim& pr,
   } else if (kind == RT_MAT_METAL) {  // metal.rs:12-28
     V3 reflected = vreflect(vunit(d), rec.normal);
     if (vdot(reflected, rec.normal) > 0.0) {
-      out.direction = vadd(reflected, vscale(rand_unit_vector(key), m.param));
+      out.direction = vadd(reflected, vscale(rand_unit_vector(key, &st), m.param));
       out.scattered = true;
     }
     out.attenuation = v3(m.albedo);
@@ -253,7 +261,7 @@ RT_DEV ShadeOut shade_hit(const DeviceScene& sc, uint32_t kind, const DPrim& pr,
     out.emits = true;
   } else {  // isotropic.rs:10-17
     out.attenuation = texture_value<STATS, SOLID>(sc, m.texture, rec.u, rec.v, rec.p, st);
-    out.direction = rand_unit_vector(key);
+    out.direction = rand_unit_vector(key, &st);
     out.scattered = true;
   }
   return out;
@@ -342,27 +350,52 @@ shade_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps, uint32_t bounce, uint3
 // that costs less than the queue traffic it replaces when shading is a few
 // hundred instructions.  Scenes with procedural or image textures take the
 // binned extend/shade pair above.
-template <bool STATS, bool MEDIA>
-__global__ void __launch_bounds__(kBlock)
+// Per-wave staging of queue appends: a wave owns kWaveStage words of LDS, hands
+// out slots with ballot + prefix count, and moves the entries to the global
+// queue when kWaveFlushAt have gathered, with one global atomic.  No workgroup
+// barrier is involved, so the waves of a workgroup never wait for one another.
+const uint32_t kWaveFlushAt = 128;
+const uint32_t kWaveStage = kWaveFlushAt + 64;
+
+// LDS writes of one wave are visible to its own later reads once they have been
+// issued in order; this keeps the compiler from moving accesses across.
+RT_DEV void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+RT_DEV void wave_flush(const uint32_t* stage, uint32_t n, uint32_t* g_counter, uint32_t* g_queue) {
+  wave_lds_sync();
+  uint32_t base = 0;
+  if (lane_id() == 0) base = atomicAdd(g_counter, n);
+  base = __builtin_amdgcn_readfirstlane(base);
+  for (uint32_t i = lane_id(); i < n; i += 64u) g_queue[base + i] = stage[i];
+  wave_lds_sync();
+}
+
+template <int BLOCK, bool STATS, bool MEDIA>
+__global__ void __launch_bounds__(BLOCK)
 trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_t bounce,
              uint32_t max_depth, unsigned long long* g_stats) {
   extern __shared__ __align__(16) char smem[];
-  __shared__ uint32_t s_next[kStageCap];
-  __shared__ uint32_t s_next_count;
-  __shared__ uint32_t s_word;
+  __shared__ uint32_t s_next[(BLOCK / 64) * kWaveStage];
   const uint32_t* live = pb.live[bounce & 1u];
   uint32_t* next_live = pb.live[(bounce + 1u) & 1u];
   uint32_t* counters = pb.counters + (size_t)bounce * kCounterStride;
   const uint32_t n_live =
       bounce == 0 ? ps.n_paths : pb.counters[(size_t)(bounce - 1) * kCounterStride + 6];
-  if (blockIdx.x * kBlock >= n_live) return;
-  if (threadIdx.x == 0) s_next_count = 0;
-  const LdsScene lds = lds_stage(sc, lay, smem, threadIdx.x, kBlock);  // ends with a barrier
+  if (blockIdx.x * (uint32_t)BLOCK >= n_live) return;
+  const LdsScene lds = lds_stage(sc, lay, smem, threadIdx.x, BLOCK);  // the only workgroup barrier
+  uint32_t* stage = s_next + (threadIdx.x / 64u) * kWaveStage;
+  uint32_t n_staged = 0;  // wave-uniform
   Stats st;
   if (STATS) st.clear();
-  const uint32_t stride = gridDim.x * kBlock;
-  for (uint32_t base = blockIdx.x * kBlock; base < n_live; base += stride) {
-    uint32_t i = base + threadIdx.x;
+  const uint32_t stride = gridDim.x * (uint32_t)BLOCK;
+  // a wave's 64 rays per trip; the trip count differs between the waves of a workgroup
+  for (uint32_t base = blockIdx.x * (uint32_t)BLOCK + (threadIdx.x & ~63u); base < n_live;
+       base += stride) {
+    uint32_t i = base + (threadIdx.x & 63u);
     bool valid = i < n_live;
     bool survives = false;
     uint32_t path = 0;
@@ -375,6 +408,7 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
       uint32_t x = ps.x0 + local % ps.ww, y = ps.y0 + local / ps.ww;
       DrawKey key{ps.seed, y * ps.width + x, ps.sample_base + s_local, bounce};
       stat<STATS>(st, RT_STAT_RAYS);
+      RT_LP(st, LP_RAY);
       Closest h = closest_hit<STATS, MEDIA>(sc, lds, o, d, ro.w, 0.001, key, st);
       // the first bounce starts from beta = 1, L = 0 (raygen wrote them; no need to read)
       V3 beta = v3(1.0, 1.0, 1.0);
@@ -391,6 +425,7 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
         pb.radiance[path] = make_double4(L.x + add.x, L.y + add.y, L.z + add.z, 0.0);
       } else {
         stat<STATS>(st, RT_STAT_HITS);
+        RT_LP(st, LP_SHADE);
         const DPrim pr = load_prim(sc, lds, h.item);
         ShadeOut so = shade_hit<STATS, true>(sc, (h.kind >> 8) & 7u, pr, o, d, ro.w, h.t, key, st);
         if (so.emits) {
@@ -408,16 +443,16 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
         }
       }
     }
-    uint32_t slot = stage_append(&s_next_count, survives);
-    if (survives) s_next[slot] = path;
-    __syncthreads();
-    uint32_t n = s_next_count;
-    if (n >= kFlushAt) stage_flush(s_next, &s_next_count, &s_word, counters + 6, next_live, n);
+    const unsigned long long mask = __ballot(survives);
+    if (survives)
+      stage[n_staged + (uint32_t)__popcll(mask & ((1ull << lane_id()) - 1ull))] = path;
+    n_staged += (uint32_t)__popcll(mask);
+    if (n_staged >= kWaveFlushAt) {
+      wave_flush(stage, n_staged, counters + 6, next_live);
+      n_staged = 0;
+    }
   }
-  {
-    uint32_t n = s_next_count;
-    if (n) stage_flush(s_next, &s_next_count, &s_word, counters + 6, next_live, n);
-  }
+  if (n_staged) wave_flush(stage, n_staged, counters + 6, next_live);
   if (STATS) flush_stats(st, g_stats);
 }
 
@@ -553,6 +588,9 @@ struct rt_ctx {
   DeviceArray<double> accum;
   DeviceArray<unsigned long long> stats;
   uint32_t* h_probe = nullptr;  // pinned word for queue-size probes
+  LdsLayout lds_trace{};        // layout for trace_kernel's workgroup size
+  uint32_t trace_block = 256;   // threads per trace_kernel workgroup: 256, 512 or 1024
+  uint32_t trace_blocks_per_cu = 16;
   std::vector<hipEvent_t> events;  // RT_FLAG_TIMING: three per bounce (before extend, between, after shade)
 };
 
@@ -648,6 +686,51 @@ int check_window(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_window* 
 
 uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); }
 
+// LDS plan for workgroups of `block` threads within `budget` bytes: the traversal
+// stack first (it is not optional), then as many top-of-tree records as fit, then
+// leaf slots with what is left.
+LdsLayout plan_lds(const FlatScene& f, uint32_t block, uint32_t budget) {
+  LdsLayout l{};
+  l.stack_depth = std::max(1u, f.stack_entries);
+  l.entry_bits = entry_code_bits((uint32_t)f.nodes.size(), (uint32_t)f.items.size());
+  uint32_t used = l.stack_depth * block * (uint32_t)sizeof(uint32_t);
+  budget = std::max(budget, used + 4096u);  // leave room for a few records
+  uint32_t room = budget - used;
+  l.n_nodes = std::min<uint32_t>((uint32_t)f.nodes.size(), room / 32u);
+  room -= l.n_nodes * 32u;
+  l.n_prims = std::min<uint32_t>((uint32_t)f.prims.size(), room / 64u);
+  l.bytes = used + l.n_nodes * 32u + l.n_prims * 64u;
+  return l;
+}
+
+template <int BLOCK>
+void launch_trace_block(rt_ctx* ctx, bool stats, bool media, uint32_t grid, const PathBuffers& pb,
+                        const PassInfo& ps, uint32_t b, uint32_t max_depth, unsigned long long* gs) {
+  const LdsLayout& l = ctx->lds_trace;
+  if (stats) {
+    if (media) trace_kernel<BLOCK, true, true><<<grid, BLOCK, l.bytes, ctx->stream>>>(ctx->ds, l, pb, ps, b, max_depth, gs);
+    else trace_kernel<BLOCK, true, false><<<grid, BLOCK, l.bytes, ctx->stream>>>(ctx->ds, l, pb, ps, b, max_depth, gs);
+  } else {
+    if (media) trace_kernel<BLOCK, false, true><<<grid, BLOCK, l.bytes, ctx->stream>>>(ctx->ds, l, pb, ps, b, max_depth, gs);
+    else trace_kernel<BLOCK, false, false><<<grid, BLOCK, l.bytes, ctx->stream>>>(ctx->ds, l, pb, ps, b, max_depth, gs);
+  }
+}
+void launch_trace(rt_ctx* ctx, bool stats, bool media, uint32_t grid, const PathBuffers& pb,
+                  const PassInfo& ps, uint32_t b, uint32_t max_depth, unsigned long long* gs) {
+  if (ctx->trace_block == 1024) launch_trace_block<1024>(ctx, stats, media, grid, pb, ps, b, max_depth, gs);
+  else if (ctx->trace_block == 512) launch_trace_block<512>(ctx, stats, media, grid, pb, ps, b, max_depth, gs);
+  else launch_trace_block<256>(ctx, stats, media, grid, pb, ps, b, max_depth, gs);
+}
+template <int BLOCK>
+hipError_t allow_trace_lds(int bytes) {
+  const hipFuncAttribute attr = hipFuncAttributeMaxDynamicSharedMemorySize;
+  hipError_t e = hipFuncSetAttribute((const void*)trace_kernel<BLOCK, false, false>, attr, bytes);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)trace_kernel<BLOCK, false, true>, attr, bytes);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)trace_kernel<BLOCK, true, false>, attr, bytes);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)trace_kernel<BLOCK, true, true>, attr, bytes);
+  return e;
+}
+
 // Render the sample range into ctx->accum (f64 sums, window-sized).
 int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats) {
   if (!ctx) return RT_ERR_INVALID;
@@ -736,18 +819,17 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats) {
                                ctx->stream));
     raygen_kernel<<<blocks_for(ps.n_paths), kBlock, 0, ctx->stream>>>(ctx->ds, pb, ps);
     uint32_t grid = std::min(blocks_for(ps.n_paths), max_grid);
+    const uint32_t tmax_grid = ctx->n_cus * std::max(1u, ctx->trace_blocks_per_cu);
+    auto trace_blocks_for = [&](uint64_t n) {
+      return (uint32_t)std::min<uint64_t>((n + ctx->trace_block - 1) / ctx->trace_block, tmax_grid);
+    };
+    uint32_t tgrid = std::max(1u, trace_blocks_for(ps.n_paths));
     for (uint32_t b = 0; b < p->max_depth; ++b) {
       unsigned long long* gs = ctx->stats.p;
       if (want_timing) RT_HIP(ctx, stamp());
       if (fused) {
         // cheap shading: traversal and scatter in one kernel per bounce
-        if (want_stats) {
-          if (media) trace_kernel<true, true><<<grid, kBlock, lds.bytes, ctx->stream>>>(ctx->ds, lds, pb, ps, b, p->max_depth, gs);
-          else trace_kernel<true, false><<<grid, kBlock, lds.bytes, ctx->stream>>>(ctx->ds, lds, pb, ps, b, p->max_depth, gs);
-        } else {
-          if (media) trace_kernel<false, true><<<grid, kBlock, lds.bytes, ctx->stream>>>(ctx->ds, lds, pb, ps, b, p->max_depth, gs);
-          else trace_kernel<false, false><<<grid, kBlock, lds.bytes, ctx->stream>>>(ctx->ds, lds, pb, ps, b, p->max_depth, gs);
-        }
+        launch_trace(ctx, want_stats, media, tgrid, pb, ps, b, p->max_depth, gs);
         if (want_timing) RT_HIP(ctx, stamp());
       } else if (want_stats) {
         if (media) extend_kernel<true, true><<<grid, kBlock, lds.bytes, ctx->stream>>>(ctx->ds, lds, pb, ps, b, gs);
@@ -773,6 +855,7 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats) {
         if (want_timing) RT_HIP(ctx, drain());
         if (live == 0) break;
         grid = std::max(1u, std::min(blocks_for(live), max_grid));
+        tgrid = std::max(1u, trace_blocks_for(live));
       }
     }
     resolve_kernel<<<blocks_for(n_pix), kBlock, 0, ctx->stream>>>(pb, ps, ctx->accum.p);
@@ -869,23 +952,33 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* scene) {
   ds.root_b = f.nodes.empty() ? 1u : f.nodes[0].b;
   ds.cam = f.camera;
   std::memcpy(ds.bg, f.background, sizeof ds.bg);
-  // LDS plan per 256-thread workgroup: the traversal stack (one entry per BVH level),
-  // then as many top-of-tree nodes as fit, then leaf slots with what is left.
+  // LDS plans.  extend/first_hit: 256-thread workgroups, four to a CU next to their
+  // 12.3 KB of staged queues.  trace: one plan per workgroup size it can run with.
   {
-    uint32_t budget = 27u * 1024u;  // with the kernels' 12.3 KB of staged queues: 4 workgroups per CU
+    uint32_t budget = 27u * 1024u;
     if (const char* e = getenv("MI355RT_LDS_BYTES")) budget = (uint32_t)strtoul(e, nullptr, 10);
-    budget = std::min(budget, 160u * 1024u);
-    LdsLayout& l = ctx->lds;
-    l.stack_depth = std::max(1u, f.stack_entries);
-    l.entry_bits = entry_code_bits((uint32_t)f.nodes.size(), (uint32_t)f.items.size());
-    uint32_t used = l.stack_depth * kBlock * (uint32_t)sizeof(uint32_t);
-    budget = std::max(budget, used + 4096u);  // the stack is not optional; leave room for a few nodes
-    uint32_t room = budget > used ? budget - used : 0u;
-    l.n_nodes = std::min<uint32_t>((uint32_t)f.nodes.size(), room / 32u);
-    room -= l.n_nodes * 32u;
-    l.n_prims = std::min<uint32_t>((uint32_t)f.prims.size(), room / 64u);
-    if (const char* e = getenv("MI355RT_LDS_PRIMS")) l.n_prims = std::min<uint32_t>(l.n_prims, (uint32_t)strtoul(e, nullptr, 10));
-    l.bytes = used + l.n_nodes * 32u + l.n_prims * 64u;
+    ctx->lds = plan_lds(f, kBlock, std::min(budget, 160u * 1024u - 13u * 1024u));
+    if (const char* e = getenv("MI355RT_LDS_PRIMS")) {
+      LdsLayout& l = ctx->lds;
+      uint32_t n = std::min<uint32_t>(l.n_prims, (uint32_t)strtoul(e, nullptr, 10));
+      l.bytes -= (l.n_prims - n) * 64u;
+      l.n_prims = n;
+    }
+    uint32_t tb = 512u;
+    if (const char* e = getenv("MI355RT_TRACE_BLOCK")) tb = (uint32_t)strtoul(e, nullptr, 10);
+    if (tb != 256u && tb != 512u && tb != 1024u)
+      return fail(ctx, RT_ERR_INVALID, "MI355RT_TRACE_BLOCK must be 256, 512 or 1024");
+    ctx->trace_block = tb;
+    // LDS of a CU split between the resident workgroups (4 waves per SIMD in all three cases),
+    // minus the per-wave queue stages
+    const uint32_t stage_bytes = (tb / 64u) * kWaveStage * 4u;
+    uint32_t tbudget = (160u * 1024u) / (1024u / tb) - stage_bytes - 1024u;
+    if (const char* e = getenv("MI355RT_TRACE_LDS_BYTES")) tbudget = (uint32_t)strtoul(e, nullptr, 10);
+    tbudget = std::min(tbudget, 160u * 1024u - stage_bytes - 512u);
+    ctx->lds_trace = plan_lds(f, tb, tbudget);
+    ctx->trace_blocks_per_cu = 4096u / tb;
+    if (const char* e = getenv("MI355RT_TRACE_BLOCKS_PER_CU"))
+      ctx->trace_blocks_per_cu = std::max(1u, (uint32_t)strtoul(e, nullptr, 10));
   }
   if (ctx->lds.bytes > 32u * 1024u) {
     int bytes = (int)ctx->lds.bytes;
@@ -895,10 +988,12 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* scene) {
     RT_HIP(ctx, hipFuncSetAttribute((const void*)extend_kernel<true, false>, attr, bytes));
     RT_HIP(ctx, hipFuncSetAttribute((const void*)extend_kernel<true, true>, attr, bytes));
     RT_HIP(ctx, hipFuncSetAttribute((const void*)first_hit_kernel, attr, bytes));
-    RT_HIP(ctx, hipFuncSetAttribute((const void*)trace_kernel<false, false>, attr, bytes));
-    RT_HIP(ctx, hipFuncSetAttribute((const void*)trace_kernel<false, true>, attr, bytes));
-    RT_HIP(ctx, hipFuncSetAttribute((const void*)trace_kernel<true, false>, attr, bytes));
-    RT_HIP(ctx, hipFuncSetAttribute((const void*)trace_kernel<true, true>, attr, bytes));
+  }
+  if (ctx->lds_trace.bytes > 32u * 1024u) {
+    int bytes = (int)ctx->lds_trace.bytes;
+    RT_HIP(ctx, ctx->trace_block == 1024 ? allow_trace_lds<1024>(bytes)
+                : ctx->trace_block == 512 ? allow_trace_lds<512>(bytes)
+                                          : allow_trace_lds<256>(bytes));
   }
   ctx->have_scene = true;
   return RT_OK;
@@ -1052,3 +1147,15 @@ void rt_destroy(rt_ctx* ctx) {
 }
 
 }  // extern "C"
+
+#ifdef RT_LANE_PROFILE
+// development build only: read and clear the loop-trip counters
+extern "C" int rt_debug_lane_trips(unsigned long long* out, int n) {
+  unsigned long long h[2 * LP_COUNT];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lane_trips), sizeof(h)) != hipSuccess) return -1;
+  for (int i = 0; i < n && i < 2 * LP_COUNT; ++i) out[i] = h[i];
+  std::memset(h, 0, sizeof(h));
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_lane_trips), h, sizeof(h)) != hipSuccess) return -1;
+  return 2 * LP_COUNT;
+}
+#endif

@@ -80,9 +80,18 @@ RT_DEV u32x4 draw(const DrawKey& k, uint32_t purpose, uint32_t seq) {
 }
 const uint32_t kMaxRejections = 4096;  // the loop ends with probability 1 - 2^-4000 long before
 
-RT_DEV V3 rand_unit_vector(const DrawKey& k) {  // vec3.rs:35-47
+#ifdef RT_LANE_PROFILE
+struct Stats;
+RT_DEV void reject_trip(Stats* st);
+#define RT_LP_REJECT(st) reject_trip(st)
+#else
+#define RT_LP_REJECT(st) ((void)0)
+#endif
+struct Stats;
+RT_DEV V3 rand_unit_vector(const DrawKey& k, Stats* st = nullptr) {  // vec3.rs:35-47
   V3 v = v3(0.0, 0.0, 0.0);
   for (uint32_t it = 0; it < kMaxRejections; ++it) {
+    RT_LP_REJECT(st);
     sym3_42(draw(k, DRAW_SCATTER, it), v.x, v.y, v.z);
     if (vlen2(v) < 1.0) break;
   }
@@ -100,13 +109,38 @@ RT_DEV V3 rand_in_unit_disk(const DrawKey& k) {  // vec3.rs:49-60
 }
 
 // ------------------------------------------------------------- statistics
+#ifdef RT_LANE_PROFILE
+// Development build only: per loop, how many wave-level trips ran and how many
+// lanes were active in them (trips[2k] = lane trips, trips[2k+1] = wave trips).
+enum { LP_RAY = 0, LP_OUTER, LP_NODE, LP_LEAFPRIM, LP_POP, LP_SHADE, LP_REJECT, LP_ROOTS, LP_COUNT };
+#endif
 struct Stats {
   uint32_t v[RT_STAT_COUNT];
+#ifdef RT_LANE_PROFILE
+  uint32_t trips[2 * LP_COUNT];
+#endif
   RT_DEV void clear() {
 #pragma unroll
     for (int i = 0; i < RT_STAT_COUNT; ++i) v[i] = 0;
+#ifdef RT_LANE_PROFILE
+#pragma unroll
+    for (int i = 0; i < 2 * LP_COUNT; ++i) trips[i] = 0;
+#endif
   }
 };
+#ifdef RT_LANE_PROFILE
+RT_DEV void lane_trip(Stats& st, int loop) {
+  unsigned long long m = __ballot(1);
+  st.trips[2 * loop]++;
+  if ((int)__lane_id() == __ffsll((long long)m) - 1) st.trips[2 * loop + 1]++;
+}
+#define RT_LP(st, loop) lane_trip(st, loop)
+RT_DEV void reject_trip(Stats* st) {
+  if (st) lane_trip(*st, LP_REJECT);
+}
+#else
+#define RT_LP(st, loop) ((void)0)
+#endif
 template <bool ON>
 RT_DEV void stat(Stats& s, int which) {
   if (ON) s.v[which]++;
@@ -212,6 +246,7 @@ RT_DEV bool sphere_t(V3 c, double radius, V3 o, V3 d, double a, double tmin, dou
   double discrim = half_b * half_b - a * cc;
   if (discrim < 0.0) return false;
   stat<STATS>(st, RT_STAT_SPHERE_ROOTS);
+  RT_LP(st, LP_ROOTS);
   double sqrtd = sqrt(discrim);
   double root = (-half_b - sqrtd) / a;
   if (!in_range(root, tmin, tmax)) {
@@ -398,10 +433,16 @@ struct LdsLayout {
   uint32_t bytes;        // total dynamic LDS bytes per workgroup
   uint32_t entry_bits;   // bits of a traversal entry code (see entry_code_bits)
 };
+// The pointers carry the LDS address space: a generic pointer that may be LDS or
+// global turns every access into a flat instruction, several times slower to
+// return than a ds_read.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
 struct LdsScene {
-  const float4* nodes;
-  const float4* prims;  // 4 x float4 per DPrim
-  uint32_t* stack;      // this lane's column of packed entries, `stack_stride` words apart
+  const lds_f32x4* nodes;
+  const lds_f32x4* prims;  // 4 x 16 bytes per DPrim
+  lds_u32* stack;          // this lane's column of packed entries, `stack_stride` words apart
   uint32_t n_nodes, n_prims, stack_stride, entry_bits;
 };
 
@@ -409,11 +450,12 @@ struct LdsScene {
 // thread of the workgroup must call this (it ends with a barrier).
 RT_DEV LdsScene lds_stage(const DeviceScene& sc, const LdsLayout& lay, char* smem, uint32_t tid,
                           uint32_t block) {
-  float4* nodes = (float4*)smem;
-  float4* prims = nodes + 2u * lay.n_nodes;
-  uint32_t* stack = (uint32_t*)(prims + 4u * lay.n_prims);
-  const float4* gp = (const float4*)sc.prims;
-  for (uint32_t i = tid; i < 2u * lay.n_nodes; i += block) nodes[i] = sc.nodes[i];
+  lds_f32x4* nodes = (lds_f32x4*)smem;
+  lds_f32x4* prims = nodes + 2u * lay.n_nodes;
+  lds_u32* stack = (lds_u32*)(prims + 4u * lay.n_prims);
+  const f32x4* gn = (const f32x4*)sc.nodes;
+  const f32x4* gp = (const f32x4*)sc.prims;
+  for (uint32_t i = tid; i < 2u * lay.n_nodes; i += block) nodes[i] = gn[i];
   for (uint32_t i = tid; i < 4u * lay.n_prims; i += block) prims[i] = gp[i];
   __syncthreads();
   LdsScene l;
@@ -429,14 +471,14 @@ RT_DEV LdsScene lds_stage(const DeviceScene& sc, const LdsLayout& lay, char* sme
 
 RT_DEV DPrim load_prim(const DeviceScene& sc, const LdsScene& lds, uint32_t slot) {
   union {
-    float4 q[4];
+    f32x4 q[4];
     DPrim p;
   } u;
   if (slot < lds.n_prims) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) u.q[k] = lds.prims[4u * slot + k];
   } else {
-    const float4* g = (const float4*)(sc.prims + slot);
+    const f32x4* g = (const f32x4*)(sc.prims + slot);
 #pragma unroll
     for (int k = 0; k < 4; ++k) u.q[k] = g[k];
   }
@@ -483,7 +525,7 @@ RT_HD uint32_t stack_t_bits(float t, uint32_t bits) {
 template <bool STATS, bool MEDIA>
 RT_DEV Closest closest_hit(const DeviceScene& sc, const LdsScene& lds, V3 o, V3 d, double time,
                            double tmin, const DrawKey& key, Stats& st) {
-  uint32_t* stack = lds.stack;
+  lds_u32* stack = lds.stack;
   const uint32_t stride = lds.stack_stride;
   const uint32_t ebits = lds.entry_bits, emask = (1u << ebits) - 1u;
   const double inf = __longlong_as_double(0x7FF0000000000000ll);
@@ -497,12 +539,14 @@ RT_DEV Closest closest_hit(const DeviceScene& sc, const LdsScene& lds, V3 o, V3 
   const float tmin32 = (float)tmin * 0.99f;
   float best32 = __int_as_float(0x7F800000);
   const double dd = vlen2(d);
+  const f32x4* gnodes = (const f32x4*)sc.nodes;
   uint32_t sp = 0;
   uint32_t cur = make_entry(sc.root_a, sc.root_b);  // the root's own box is not tested
 
   // next entry from the stack that can still matter, or kNoEntry
   auto pop = [&]() -> uint32_t {
     while (sp) {
+      RT_LP(st, LP_POP);
       uint32_t w = stack[(--sp) * stride];
       if (__uint_as_float((w >> ebits) << (ebits - 1u)) <= best32 * kWiden) return w & emask;
     }
@@ -510,6 +554,7 @@ RT_DEV Closest closest_hit(const DeviceScene& sc, const LdsScene& lds, V3 o, V3 
   };
 
   for (;;) {
+    RT_LP(st, LP_OUTER);
     // descend until the current entry is a leaf
     uint32_t leaf = kNoEntry;
     while (cur != kNoEntry) {
@@ -517,6 +562,7 @@ RT_DEV Closest closest_hit(const DeviceScene& sc, const LdsScene& lds, V3 o, V3 
         leaf = cur;
         break;
       }
+      RT_LP(st, LP_NODE);
       const uint32_t first = cur >> 3, n = ((cur >> 1) & 3u) + 1u;
       const bool in_lds = first + 4u <= lds.n_nodes;
       uint32_t near_entry = kNoEntry;
@@ -524,13 +570,13 @@ RT_DEV Closest closest_hit(const DeviceScene& sc, const LdsScene& lds, V3 o, V3 
 #pragma unroll
       for (uint32_t k = 0; k < 4; ++k) {
         if (k < n) {
-          float4 n0, n1;
+          f32x4 n0, n1;
           if (in_lds) {
             n0 = lds.nodes[2 * (first + k)];
             n1 = lds.nodes[2 * (first + k) + 1];
           } else {
-            n0 = sc.nodes[2 * (first + k)];
-            n1 = sc.nodes[2 * (first + k) + 1];
+            n0 = gnodes[2 * (first + k)];
+            n1 = gnodes[2 * (first + k) + 1];
           }
           stat<STATS>(st, RT_STAT_BOX_TESTS);
           float ax = fmaf(n0.x, cx.inv, cx.noi_lo), bx = fmaf(n0.w, cx.inv, cx.noi_hi);
@@ -559,6 +605,7 @@ RT_DEV Closest closest_hit(const DeviceScene& sc, const LdsScene& lds, V3 o, V3 
     if (leaf == kNoEntry) break;
     const uint32_t leaf_first = leaf >> 4, leaf_count = ((leaf >> 1) & 7u) + 1u;
     for (uint32_t k = 0; k < leaf_count; ++k) {
+      RT_LP(st, LP_LEAFPRIM);
       uint32_t slot = leaf_first + k;
       const DPrim pr = load_prim(sc, lds, slot);
       double t;

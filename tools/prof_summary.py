@@ -9,7 +9,7 @@ import sys
 
 
 def short(name):
-    for k in ("extend_kernel", "shade_kernel", "raygen_kernel", "resolve_kernel", "first_hit_kernel",
+    for k in ("trace_kernel", "extend_kernel", "shade_kernel", "raygen_kernel", "resolve_kernel", "first_hit_kernel",
               "to_float_kernel"):
         if k in name:
             tail = name[name.index(k):].split("(")[0]
