@@ -1048,11 +1048,11 @@ struct FlatBvh {
 
 // Closest hit over the flattened (up to four-wide) BVH, walked the way the device
 // walks it: a visit of an interior record slab-tests its consecutive children in
-// f32 against [t_start, best t], goes on with the hit child that is entered
-// first (strictly: the earlier child keeps a tie) and stacks the other hit
-// children with their entry parameter; a popped entry whose entry parameter lies
-// beyond the best t by now is dropped.  The root's own box is not tested.  Ties
-// on t resolve to the lower rank.
+// f32 against [t_start, best t]; the hit children are ordered by (entry parameter
+// with its low bits cleared, entry code); the walk goes on with the first and
+// stacks the others, last first; a popped entry whose (truncated) entry parameter
+// lies beyond the best t by now is dropped.  The root's own box is not tested.
+// Ties on t resolve to the lower rank.
 OptHit flat_hit(const SceneData& sc, const FlatBvh& bvh, const Ray& ray, Range t_range,
                 const HitCtx& cx) {
   OptHit best;
@@ -1094,6 +1094,16 @@ OptHit flat_hit(const SceneData& sc, const FlatBvh& bvh, const Ray& ray, Range t
     uint32_t node;  // record index
     float t;
   };
+  // what a record stands for, as one number: the device's second sort key
+  auto entry_code = [](const rt_bvh_node& c) -> uint32_t {
+    if (c.b & 0x80000000u) return ((c.a << 2) | (c.b & 3u)) << 1;
+    return (((c.a << 3) | (c.b - 1u)) << 1) | 1u;
+  };
+  auto float_bits = [](float t) {
+    uint32_t u;
+    std::memcpy(&u, &t, 4);
+    return u;
+  };
   std::vector<Entry> stack;
   auto pop = [&](uint32_t& out) -> bool {
     while (!stack.empty()) {
@@ -1113,9 +1123,12 @@ OptHit flat_hit(const SceneData& sc, const FlatBvh& bvh, const Ray& ray, Range t
     uint32_t next = 0;
     if (n.b & 0x80000000u) {
       uint32_t kids = (n.b & 3u) + 1u;
-      float near_t = finf;
-      bool have_near = false;
-      uint32_t near = 0;
+      struct Hit {
+        uint64_t key;
+        Entry e;
+      };
+      Hit hits[4];
+      uint32_t n_hits = 0;
       for (uint32_t k = 0; k < kids; ++k) {
         const rt_bvh_node& c = bvh.nodes[n.a + k];
         if (cx.count) cx.count->v[RT_STAT_BOX_TESTS]++;
@@ -1129,17 +1142,15 @@ OptHit flat_hit(const SceneData& sc, const FlatBvh& bvh, const Ray& ray, Range t
         float t0 = std::fmax(std::fmax(lo3[0], lo3[1]), std::fmax(lo3[2], tmin32));
         float t1 = std::fmin(std::fmin(hi3[0], hi3[1]), std::fmin(hi3[2], best32));
         if (!(t0 <= t1 * widen)) continue;
-        if (t0 < near_t) {
-          if (have_near) stack.push_back(Entry{near, truncated(near_t)});
-          near = n.a + k;
-          near_t = t0;
-          have_near = true;
-        } else {
-          stack.push_back(Entry{n.a + k, truncated(t0)});
-        }
+        float tt = truncated(t0);
+        hits[n_hits].key = ((uint64_t)float_bits(tt) << 32) | entry_code(c);
+        hits[n_hits].e = Entry{n.a + k, tt};
+        ++n_hits;
       }
-      if (have_near) {
-        next = near;
+      std::sort(hits, hits + n_hits, [](const Hit& x, const Hit& y) { return x.key < y.key; });
+      for (uint32_t k = n_hits; k > 1; --k) stack.push_back(hits[k - 1].e);
+      if (n_hits) {
+        next = hits[0].e.node;
         have_next = true;
       }
     } else {

@@ -22,6 +22,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <limits>
 #include <vector>
 
 #include "rt_device.h"
@@ -691,12 +692,13 @@ uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); 
 // leaf slots with what is left.
 LdsLayout plan_lds(const FlatScene& f, uint32_t block, uint32_t budget) {
   LdsLayout l{};
-  l.stack_depth = std::max(1u, f.stack_entries);
+  l.stack_depth = f.stack_entries + 1u;  // one spare: a visit stores before it knows whether it keeps
   l.entry_bits = entry_code_bits((uint32_t)f.nodes.size(), (uint32_t)f.items.size());
   uint32_t used = l.stack_depth * block * (uint32_t)sizeof(uint32_t);
   budget = std::max(budget, used + 4096u);  // leave room for a few records
   uint32_t room = budget - used;
-  l.n_nodes = std::min<uint32_t>((uint32_t)f.nodes.size(), room / 32u);
+  // (+3: the never-hit records that end the device copy, so the last group stays in LDS)
+  l.n_nodes = std::min<uint32_t>((uint32_t)f.nodes.size() + 3u, room / 32u);
   room -= l.n_nodes * 32u;
   l.n_prims = std::min<uint32_t>((uint32_t)f.prims.size(), room / 64u);
   l.bytes = used + l.n_nodes * 32u + l.n_prims * 64u;
@@ -923,7 +925,23 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* scene) {
   if (!err.empty()) return fail(ctx, code, err);
   const FlatScene& f = ctx->flat;
   int rc;
-  if ((rc = upload(ctx, ctx->nodes, f.nodes)) != RT_OK) return rc;
+  {
+    // device copy of the records: the traversal entry code in place of `a`, and three
+    // never-hit records at the end so that a visit may always read four children
+    std::vector<rt_bvh_node> dn = f.nodes;
+    for (rt_bvh_node& n : dn) {
+      n.a = make_entry(n.a, n.b);
+      n.b = 0;
+    }
+    rt_bvh_node pad{};
+    for (int a = 0; a < 3; ++a) {
+      pad.lo[a] = std::numeric_limits<float>::infinity();
+      pad.hi[a] = -std::numeric_limits<float>::infinity();
+    }
+    pad.a = 0xFFFFFFFFu;
+    for (int k = 0; k < 3; ++k) dn.push_back(pad);
+    if ((rc = upload(ctx, ctx->nodes, dn)) != RT_OK) return rc;
+  }
   if ((rc = upload(ctx, ctx->prims, f.prims)) != RT_OK) return rc;
   if ((rc = upload(ctx, ctx->ranks, f.ranks)) != RT_OK) return rc;
   if ((rc = upload(ctx, ctx->boundary, f.boundary)) != RT_OK) return rc;
@@ -948,8 +966,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* scene) {
   ds.texels = ctx->texels.p;
   ds.n_nodes = (uint32_t)f.nodes.size();
   ds.has_media = f.has_media ? 1u : 0u;
-  ds.root_a = f.nodes.empty() ? 0u : f.nodes[0].a;
-  ds.root_b = f.nodes.empty() ? 1u : f.nodes[0].b;
+  ds.root_code = f.nodes.empty() ? 1u : make_entry(f.nodes[0].a, f.nodes[0].b);
   ds.cam = f.camera;
   std::memcpy(ds.bg, f.background, sizeof ds.bg);
   // LDS plans.  extend/first_hit: 256-thread workgroups, four to a CU next to their

@@ -30,7 +30,7 @@ struct DeviceScene {
   const uint8_t* texels;
   uint32_t n_nodes;
   uint32_t has_media;
-  uint32_t root_a, root_b;  // the root record's (a, b)
+  uint32_t root_code;  // traversal entry code of the root record
   rt_camera cam;
   double bg[3];
 };
@@ -489,13 +489,17 @@ RT_DEV DPrim load_prim(const DeviceScene& sc, const LdsScene& lds, uint32_t slot
 //
 // A traversal entry is a code for what a record's (a, b) say:
 //   interior: ((first child << 2) | (children - 1)) << 1;  leaf: (((first item << 3) | (count - 1)) << 1) | 1.
-// A visit of an interior entry reads its (up to four, consecutive) child records,
-// slab-tests each against [tmin, best t], continues with the hit child that is
-// entered first and pushes the other hit children together with their entry
-// parameter; a popped entry whose entry parameter now lies beyond the best t is
-// dropped.  A stack word holds the code in its low `entry_bits` bits and, above
-// them, as many leading bits of the (positive) f32 entry parameter as fit:
-// truncation rounds the parameter down, which only makes the drop test keep more.
+// The device copy of a record holds that code in place of `a` (see device_nodes).
+// A visit of an interior entry reads its four consecutive child records at once
+// (fewer than four children: the extra records are read and ignored), slab-tests
+// each against [tmin, best t] and forms one 32-bit word per child: the code in the
+// low `entry_bits` bits and, above them, as many leading bits of the (positive)
+// f32 entry parameter as fit (truncation rounds the parameter down, which only
+// makes later drop tests keep more); a missed child gives 0xFFFFFFFF.  The four
+// words are sorted as unsigned integers, which orders them by entry parameter:
+// the traversal continues with the smallest and stacks the other hits, farthest
+// first.  A popped word whose entry parameter now lies beyond the best t is
+// dropped.  The whole visit is free of branches.
 // Primitive tests always use the reference's full range tmin..inf so that equal
 // t can be resolved by rank.
 const uint32_t kNoEntry = 0xFFFFFFFFu;
@@ -541,7 +545,7 @@ RT_DEV Closest closest_hit(const DeviceScene& sc, const LdsScene& lds, V3 o, V3 
   const double dd = vlen2(d);
   const f32x4* gnodes = (const f32x4*)sc.nodes;
   uint32_t sp = 0;
-  uint32_t cur = make_entry(sc.root_a, sc.root_b);  // the root's own box is not tested
+  uint32_t cur = sc.root_code;  // the root's own box is not tested
 
   // next entry from the stack that can still matter, or kNoEntry
   auto pop = [&]() -> uint32_t {
@@ -565,42 +569,46 @@ RT_DEV Closest closest_hit(const DeviceScene& sc, const LdsScene& lds, V3 o, V3 
       RT_LP(st, LP_NODE);
       const uint32_t first = cur >> 3, n = ((cur >> 1) & 3u) + 1u;
       const bool in_lds = first + 4u <= lds.n_nodes;
-      uint32_t near_entry = kNoEntry;
-      float near_t = __int_as_float(0x7F800000);
+      f32x4 r[8];
+      if (in_lds) {
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) r[k] = lds.nodes[2 * first + k];
+      } else {
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) r[k] = gnodes[2 * first + k];
+      }
+      if (STATS) st.v[RT_STAT_BOX_TESTS] += n;
+      uint32_t w[4];
 #pragma unroll
       for (uint32_t k = 0; k < 4; ++k) {
-        if (k < n) {
-          f32x4 n0, n1;
-          if (in_lds) {
-            n0 = lds.nodes[2 * (first + k)];
-            n1 = lds.nodes[2 * (first + k) + 1];
-          } else {
-            n0 = gnodes[2 * (first + k)];
-            n1 = gnodes[2 * (first + k) + 1];
-          }
-          stat<STATS>(st, RT_STAT_BOX_TESTS);
-          float ax = fmaf(n0.x, cx.inv, cx.noi_lo), bx = fmaf(n0.w, cx.inv, cx.noi_hi);
-          float ay = fmaf(n0.y, cy.inv, cy.noi_lo), by = fmaf(n1.x, cy.inv, cy.noi_hi);
-          float az = fmaf(n0.z, cz.inv, cz.noi_lo), bz = fmaf(n1.y, cz.inv, cz.noi_hi);
-          float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin32));
-          float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best32));
-          if (t0 <= t1 * kWiden) {
-            uint32_t e = make_entry(__float_as_uint(n1.z), __float_as_uint(n1.w));
-            if (t0 < near_t) {  // strict: the earlier child keeps a tie
-              if (near_entry != kNoEntry) {
-                stack[sp * stride] = ((__float_as_uint(near_t) >> (ebits - 1u)) << ebits) | near_entry;
-                ++sp;
-              }
-              near_entry = e;
-              near_t = t0;
-            } else {
-              stack[sp * stride] = ((__float_as_uint(t0) >> (ebits - 1u)) << ebits) | e;
-              ++sp;
-            }
-          }
-        }
+        const f32x4 n0 = r[2 * k], n1 = r[2 * k + 1];
+        float ax = fmaf(n0.x, cx.inv, cx.noi_lo), bx = fmaf(n0.w, cx.inv, cx.noi_hi);
+        float ay = fmaf(n0.y, cy.inv, cy.noi_lo), by = fmaf(n1.x, cy.inv, cy.noi_hi);
+        float az = fmaf(n0.z, cz.inv, cz.noi_lo), bz = fmaf(n1.y, cz.inv, cz.noi_hi);
+        float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin32));
+        float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best32));
+        const uint32_t word = ((__float_as_uint(t0) >> (ebits - 1u)) << ebits) | __float_as_uint(n1.z);
+        w[k] = (k < n && t0 <= t1 * kWiden) ? word : kNoEntry;
       }
-      cur = near_entry != kNoEntry ? near_entry : pop();
+      // sort ascending (five compare-exchanges)
+      {
+        uint32_t a0 = min(w[0], w[1]), a1 = max(w[0], w[1]);
+        uint32_t a2 = min(w[2], w[3]), a3 = max(w[2], w[3]);
+        uint32_t b0 = min(a0, a2), b2 = max(a0, a2);
+        uint32_t b1 = min(a1, a3), b3 = max(a1, a3);
+        w[0] = b0;
+        w[1] = min(b1, b2);
+        w[2] = max(b1, b2);
+        w[3] = b3;
+      }
+      // stack the far hits, farthest first; a miss is overwritten by the next store
+      stack[sp * stride] = w[3];
+      sp += w[3] != kNoEntry ? 1u : 0u;
+      stack[sp * stride] = w[2];
+      sp += w[2] != kNoEntry ? 1u : 0u;
+      stack[sp * stride] = w[1];
+      sp += w[1] != kNoEntry ? 1u : 0u;
+      cur = w[0] != kNoEntry ? (w[0] & emask) : pop();
     }
     if (leaf == kNoEntry) break;
     const uint32_t leaf_first = leaf >> 4, leaf_count = ((leaf >> 1) & 7u) + 1u;
