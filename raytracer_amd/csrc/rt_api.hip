@@ -109,6 +109,29 @@ RT_DEV void flush_stats(const Stats& st, unsigned long long* g) {
 }
 
 // --------------------------------------------------------------- raygen
+// The camera ray of one path: jitter (main.rs:91-93) and Camera::get_ray (camera.rs:22-36).
+RT_DEV void camera_ray(const DeviceScene& sc, const PassInfo& ps, uint32_t x, uint32_t y,
+                       const DrawKey& key, V3& origin, V3& dir, double& time) {
+  u32x4 j = draw(key, DRAW_JITTER, 0);
+  double jx = u01_53(j.x, j.y), jy = u01_53(j.z, j.w);
+  double u = ((double)x + jx) / ((double)ps.width - 1.0);
+  double v = ((double)(ps.height - y) + jy) / ((double)ps.height - 1.0);
+  const rt_camera& c = sc.cam;
+  V3 rd = vscale(rand_in_unit_disk(key), c.lens_radius);
+  V3 offset = vadd(vscale(v3(c.u), rd.x), vscale(v3(c.v), rd.y));
+  if (c.time1 > c.time0) {
+    u32x4 tb = draw(key, DRAW_TIME, 0);
+    time = c.time0 + (c.time1 - c.time0) * u01_53(tb.x, tb.y);
+  } else {
+    time = c.time0;
+  }
+  origin = vadd(v3(c.origin), offset);
+  dir = vsub(vsub(vadd(vadd(v3(c.lower_left), vscale(v3(c.horizontal), u)),
+                       vscale(v3(c.vertical), v)),
+                  v3(c.origin)),
+             offset);
+}
+
 __global__ void __launch_bounds__(kBlock)
 raygen_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps) {
   uint32_t path = blockIdx.x * kBlock + threadIdx.x;
@@ -116,27 +139,9 @@ raygen_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps) {
   uint32_t local = path % ps.n_pixels, s_local = path / ps.n_pixels;
   uint32_t x = ps.x0 + local % ps.ww, y = ps.y0 + local / ps.ww;
   DrawKey key{ps.seed, y * ps.width + x, ps.sample_base + s_local, 0u};
-  u32x4 j = draw(key, DRAW_JITTER, 0);
-  double jx = u01_53(j.x, j.y), jy = u01_53(j.z, j.w);
-  // main.rs:91-93
-  double u = ((double)x + jx) / ((double)ps.width - 1.0);
-  double v = ((double)(ps.height - y) + jy) / ((double)ps.height - 1.0);
-  // Camera::get_ray, camera.rs:22-36
-  const rt_camera& c = sc.cam;
-  V3 rd = vscale(rand_in_unit_disk(key), c.lens_radius);
-  V3 offset = vadd(vscale(v3(c.u), rd.x), vscale(v3(c.v), rd.y));
+  V3 origin, dir;
   double time;
-  if (c.time1 > c.time0) {
-    u32x4 tb = draw(key, DRAW_TIME, 0);
-    time = c.time0 + (c.time1 - c.time0) * u01_53(tb.x, tb.y);
-  } else {
-    time = c.time0;
-  }
-  V3 origin = vadd(v3(c.origin), offset);
-  V3 dir = vsub(vsub(vadd(vadd(v3(c.lower_left), vscale(v3(c.horizontal), u)),
-                          vscale(v3(c.vertical), v)),
-                     v3(c.origin)),
-                offset);
+  camera_ray(sc, ps, x, y, key, origin, dir, time);
   pb.ray_o[path] = make_double4(origin.x, origin.y, origin.z, time);
   pb.ray_d[path] = make_double4(dir.x, dir.y, dir.z, 0.0);
   pb.beta[path] = make_double4(1.0, 1.0, 1.0, 0.0);
@@ -402,46 +407,57 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
     uint32_t path = 0;
     if (valid) {
       path = bounce == 0 ? i : live[i];
-      double4 ro = pb.ray_o[path];
-      double4 rdv = pb.ray_d[path];
-      V3 o = v3(ro.x, ro.y, ro.z), d = v3(rdv.x, rdv.y, rdv.z);
       uint32_t s_local = path / ps.n_pixels, local = path % ps.n_pixels;
       uint32_t x = ps.x0 + local % ps.ww, y = ps.y0 + local / ps.ww;
       DrawKey key{ps.seed, y * ps.width + x, ps.sample_base + s_local, bounce};
-      stat<STATS>(st, RT_STAT_RAYS);
-      RT_LP(st, LP_RAY);
-      Closest h = closest_hit<STATS, MEDIA>(sc, lds, o, d, ro.w, 0.001, key, st);
-      // the first bounce starts from beta = 1, L = 0 (raygen wrote them; no need to read)
+      V3 o, d;
+      double time;
+      // the first bounce makes its own camera ray and starts from beta = 1, L = 0
       V3 beta = v3(1.0, 1.0, 1.0);
-      if (bounce != 0) {
+      if (bounce == 0) {
+        camera_ray(sc, ps, x, y, key, o, d, time);
+      } else {
+        double4 ro = pb.ray_o[path];
+        double4 rdv = pb.ray_d[path];
         double4 bt = pb.beta[path];
+        o = v3(ro.x, ro.y, ro.z);
+        d = v3(rdv.x, rdv.y, rdv.z);
+        time = ro.w;
         beta = v3(bt.x, bt.y, bt.z);
       }
+      stat<STATS>(st, RT_STAT_RAYS);
+      RT_LP(st, LP_RAY);
+      Closest h = closest_hit<STATS, MEDIA>(sc, lds, o, d, time, 0.001, key, st);
+      V3 add = v3(0.0, 0.0, 0.0);
+      bool adds = false;
       if (h.item == kNoPrim) {
         // miss: the recursion returns `background` (main.rs:137-139)
         stat<STATS>(st, RT_STAT_SHADE_MISS);
-        V3 add = vmul(beta, v3(sc.bg));
-        double4 L = make_double4(0.0, 0.0, 0.0, 0.0);
-        if (bounce != 0) L = pb.radiance[path];
-        pb.radiance[path] = make_double4(L.x + add.x, L.y + add.y, L.z + add.z, 0.0);
+        add = vmul(beta, v3(sc.bg));
+        adds = true;
       } else {
         stat<STATS>(st, RT_STAT_HITS);
         RT_LP(st, LP_SHADE);
         const DPrim pr = load_prim(sc, lds, h.item);
-        ShadeOut so = shade_hit<STATS, true>(sc, (h.kind >> 8) & 7u, pr, o, d, ro.w, h.t, key, st);
+        ShadeOut so = shade_hit<STATS, true>(sc, (h.kind >> 8) & 7u, pr, o, d, time, h.t, key, st);
         if (so.emits) {
-          double4 L = make_double4(0.0, 0.0, 0.0, 0.0);
-          if (bounce != 0) L = pb.radiance[path];
-          V3 add = vmul(beta, so.emitted);
-          pb.radiance[path] = make_double4(L.x + add.x, L.y + add.y, L.z + add.z, 0.0);
+          add = vmul(beta, so.emitted);
+          adds = true;
         }
         if (so.scattered && bounce + 1u < max_depth) {
           survives = true;
           V3 nb = vmul(beta, so.attenuation);
           pb.beta[path] = make_double4(nb.x, nb.y, nb.z, 0.0);
-          pb.ray_o[path] = make_double4(so.p.x, so.p.y, so.p.z, ro.w);
+          pb.ray_o[path] = make_double4(so.p.x, so.p.y, so.p.z, time);
           pb.ray_d[path] = make_double4(so.direction.x, so.direction.y, so.direction.z, 0.0);
         }
+      }
+      // L += add; the first bounce also starts every path's L
+      if (bounce == 0) {
+        pb.radiance[path] = make_double4(0.0 + add.x, 0.0 + add.y, 0.0 + add.z, 0.0);
+      } else if (adds) {
+        double4 L = pb.radiance[path];
+        pb.radiance[path] = make_double4(L.x + add.x, L.y + add.y, L.z + add.z, 0.0);
       }
     }
     const unsigned long long mask = __ballot(survives);
@@ -633,9 +649,10 @@ void free_paths(rt_ctx* ctx) {
   ctx->counters_depth = 0;
 }
 
-int ensure_paths(rt_ctx* ctx, uint64_t capacity, uint32_t max_depth) {
+int ensure_paths(rt_ctx* ctx, uint64_t capacity, uint32_t max_depth, bool binned) {
   PathBuffers& pb = ctx->pb;
-  if (capacity > ctx->pb_capacity) {
+  if (capacity > ctx->pb_capacity || (binned && !pb.bins)) {
+    capacity = std::max(capacity, ctx->pb_capacity);
     uint32_t* keep_counters = pb.counters;
     uint32_t keep_depth = ctx->counters_depth;
     pb.counters = nullptr;
@@ -646,10 +663,12 @@ int ensure_paths(rt_ctx* ctx, uint64_t capacity, uint32_t max_depth) {
     RT_HIP(ctx, hipMalloc((void**)&pb.ray_d, capacity * sizeof(double4)));
     RT_HIP(ctx, hipMalloc((void**)&pb.beta, capacity * sizeof(double4)));
     RT_HIP(ctx, hipMalloc((void**)&pb.radiance, capacity * sizeof(double4)));
-    RT_HIP(ctx, hipMalloc((void**)&pb.hit_item, capacity * sizeof(uint32_t)));
     RT_HIP(ctx, hipMalloc((void**)&pb.live[0], capacity * sizeof(uint32_t)));
     RT_HIP(ctx, hipMalloc((void**)&pb.live[1], capacity * sizeof(uint32_t)));
-    RT_HIP(ctx, hipMalloc((void**)&pb.bins, capacity * kBins * sizeof(uint32_t)));
+    if (binned) {  // only the extend / shade pipeline records hits and bins paths
+      RT_HIP(ctx, hipMalloc((void**)&pb.hit_item, capacity * sizeof(uint32_t)));
+      RT_HIP(ctx, hipMalloc((void**)&pb.bins, capacity * kBins * sizeof(uint32_t)));
+    }
     pb.capacity = capacity;
     ctx->pb_capacity = capacity;
   }
@@ -795,9 +814,7 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats) {
 
   uint32_t per_pass = (uint32_t)std::min<uint64_t>(ctx->max_paths / n_pix, n_samples);
   if (per_pass == 0) per_pass = 1;
-  rc = ensure_paths(ctx, n_pix * per_pass, p->max_depth);
-  if (rc != RT_OK) return rc;
-  const PathBuffers pb = ctx->pb;
+  const PathBuffers& pb = ctx->pb;
   uint32_t blocks_per_cu = 16u;
   if (const char* e = getenv("MI355RT_BLOCKS_PER_CU")) blocks_per_cu = (uint32_t)strtoul(e, nullptr, 10);
   const uint32_t max_grid = ctx->n_cus * std::max(1u, blocks_per_cu);
@@ -810,6 +827,8 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats) {
   uint32_t bins_present = 1u;
   for (const DMaterial& m : ctx->flat.materials) bins_present |= 2u << m.kind;
   const LdsLayout lds = ctx->lds;
+  rc = ensure_paths(ctx, n_pix * per_pass, p->max_depth, !fused);
+  if (rc != RT_OK) return rc;
 
   for (uint32_t done = 0; done < n_samples; done += per_pass) {
     ps.samples = std::min(per_pass, n_samples - done);
@@ -819,7 +838,8 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats) {
     RT_HIP(ctx, hipMemsetAsync(pb.counters, 0,
                                (size_t)p->max_depth * kCounterStride * sizeof(uint32_t),
                                ctx->stream));
-    raygen_kernel<<<blocks_for(ps.n_paths), kBlock, 0, ctx->stream>>>(ctx->ds, pb, ps);
+    if (!fused)  // the fused kernel makes the camera rays in its first bounce
+      raygen_kernel<<<blocks_for(ps.n_paths), kBlock, 0, ctx->stream>>>(ctx->ds, pb, ps);
     uint32_t grid = std::min(blocks_for(ps.n_paths), max_grid);
     const uint32_t tmax_grid = ctx->n_cus * std::max(1u, ctx->trace_blocks_per_cu);
     auto trace_blocks_for = [&](uint64_t n) {
@@ -889,7 +909,6 @@ int rt_create(const rt_config* cfg, rt_ctx** out) {
   rt_ctx* ctx = new (std::nothrow) rt_ctx();
   if (!ctx) return RT_ERR_NOMEM;
   ctx->device = cfg ? cfg->device : 0;
-  ctx->max_paths = cfg && cfg->max_paths_in_flight ? cfg->max_paths_in_flight : (1ull << 25);
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
   if (e != hipSuccess || count <= 0 || ctx->device < 0 || ctx->device >= count) {
@@ -906,6 +925,16 @@ int rt_create(const rt_config* cfg, rt_ctx** out) {
     return RT_ERR_DEVICE;
   }
   ctx->n_cus = (uint32_t)prop.multiProcessorCount;
+  if (cfg && cfg->max_paths_in_flight) {
+    ctx->max_paths = cfg->max_paths_in_flight;
+  } else {
+    // default: a quarter of the free device memory at ~160 bytes of state per path,
+    // between 2^22 and 2^27 paths (fewer, larger passes spend less time in their tails)
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+    uint64_t fit = (uint64_t)(free_b / 4) / 160u;
+    ctx->max_paths = std::min<uint64_t>(std::max<uint64_t>(fit, 1ull << 22), 1ull << 27);
+  }
   *out = ctx;
   return RT_OK;
 }
@@ -997,6 +1026,11 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* scene) {
     if (const char* e = getenv("MI355RT_TRACE_BLOCKS_PER_CU"))
       ctx->trace_blocks_per_cu = std::max(1u, (uint32_t)strtoul(e, nullptr, 10));
   }
+  if (getenv("MI355RT_DEBUG"))
+    fprintf(stderr, "mi355rt: %zu records, %zu leaf slots, stack %u; extend LDS %u B (%u records, %u slots); "
+            "trace block %u LDS %u B (%u records, %u slots)\n", f.nodes.size(), f.prims.size(),
+            f.stack_entries, ctx->lds.bytes, ctx->lds.n_nodes, ctx->lds.n_prims, ctx->trace_block,
+            ctx->lds_trace.bytes, ctx->lds_trace.n_nodes, ctx->lds_trace.n_prims);
   if (ctx->lds.bytes > 32u * 1024u) {
     int bytes = (int)ctx->lds.bytes;
     const hipFuncAttribute attr = hipFuncAttributeMaxDynamicSharedMemorySize;
