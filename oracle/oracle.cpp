@@ -1060,21 +1060,30 @@ OptHit flat_hit(const SceneData& sc, const FlatBvh& bvh, const Ray& ray, Range t
   if (bvh.n_nodes == 0) return best;
   // f32 slab constants per axis; every step is a correctly rounded IEEE f32
   // operation, repeated here exactly as the device performs it
-  float inv[3], noi_lo[3], noi_hi[3];
+  // (the plane a ray leaves a slab through carries the widening factor in its constants)
+  const float widen = 1.000003814697265625f;  // 1 + 2^-18
+  float inv_lo[3], add_lo[3], inv_hi[3], add_hi[3];
   for (int a = 0; a < 3; ++a) {
     float d32 = (float)ray.direction[a], o32 = (float)ray.origin[a];
     float iv = 1.0f / d32;
     if (!(std::fabs(iv) <= 1e25f)) iv = std::copysign(1e25f, d32);
     float n = -(o32 * iv);
     float e = std::fabs(n) * 4.76837158203125e-07f;  // 2^-21
-    inv[a] = iv;
-    noi_lo[a] = iv >= 0.0f ? n - e : n + e;
-    noi_hi[a] = iv >= 0.0f ? n + e : n - e;
+    if (iv >= 0.0f) {
+      inv_lo[a] = iv;
+      add_lo[a] = n - e;
+      inv_hi[a] = iv * widen;
+      add_hi[a] = (n + e) * widen;
+    } else {
+      inv_lo[a] = iv * widen;
+      add_lo[a] = (n + e) * widen;
+      inv_hi[a] = iv;
+      add_hi[a] = n - e;
+    }
   }
   const float tmin32 = (float)t_range.start * 0.99f;
-  const float widen = 1.000003814697265625f;  // 1 + 2^-18
   const float finf = std::numeric_limits<float>::infinity();
-  float best32 = finf;
+  float best32w = finf;  // best t so far, times the widening factor
   // a stack word keeps only the leading bits of the entry parameter that fit beside the
   // entry code: the low (ebits - 1) float bits are cleared (rounds down)
   uint32_t ebits;
@@ -1109,7 +1118,7 @@ OptHit flat_hit(const SceneData& sc, const FlatBvh& bvh, const Ray& ray, Range t
     while (!stack.empty()) {
       Entry e = stack.back();
       stack.pop_back();
-      if (e.t <= best32 * widen) {
+      if (e.t <= best32w) {
         out = e.node;
         return true;
       }
@@ -1134,14 +1143,14 @@ OptHit flat_hit(const SceneData& sc, const FlatBvh& bvh, const Ray& ray, Range t
         if (cx.count) cx.count->v[RT_STAT_BOX_TESTS]++;
         float lo3[3], hi3[3];
         for (int a = 0; a < 3; ++a) {
-          float ta = std::fmaf(c.lo[a], inv[a], noi_lo[a]);
-          float tb = std::fmaf(c.hi[a], inv[a], noi_hi[a]);
+          float ta = std::fmaf(c.lo[a], inv_lo[a], add_lo[a]);
+          float tb = std::fmaf(c.hi[a], inv_hi[a], add_hi[a]);
           lo3[a] = std::fmin(ta, tb);
           hi3[a] = std::fmax(ta, tb);
         }
         float t0 = std::fmax(std::fmax(lo3[0], lo3[1]), std::fmax(lo3[2], tmin32));
-        float t1 = std::fmin(std::fmin(hi3[0], hi3[1]), std::fmin(hi3[2], best32));
-        if (!(t0 <= t1 * widen)) continue;
+        float t1 = std::fmin(std::fmin(hi3[0], hi3[1]), std::fmin(hi3[2], best32w));
+        if (!(t0 <= t1)) continue;
         float tt = truncated(t0);
         hits[n_hits].key = ((uint64_t)float_bits(tt) << 32) | entry_code(c);
         hits[n_hits].e = Entry{n.a + k, tt};
@@ -1165,7 +1174,7 @@ OptHit flat_hit(const SceneData& sc, const FlatBvh& bvh, const Ray& ray, Range t
         if (!best.some || r.rec.t < best.rec.t || (r.rec.t == best.rec.t && it.rank < best_rank)) {
           best = r;
           best_rank = it.rank;
-          best32 = (float)r.rec.t;
+          best32w = (float)r.rec.t * widen;
         }
       }
     }

@@ -218,18 +218,26 @@ extend_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32
 // material kind `kind` (src/material/*.rs, src/texture/isotropic.rs).
 struct ShadeOut {
   V3 attenuation, direction, emitted, p;
+  double fuzz;      // metal: scale of the random vector
+  uint32_t kind;
   bool scattered, emits;
+  bool needs_vector;  // direction still lacks its random unit vector (shade_finish)
 };
 
+// First half: everything up to the material's random unit vector.  For Lambertian,
+// Metal and Isotropic hits `direction` holds what the vector is added to.
 template <bool STATS, bool SOLID>
-RT_DEV ShadeOut shade_hit(const DeviceScene& sc, uint32_t kind, const DPrim& pr, V3 o, V3 d,
-                          double time, double t, const DrawKey& key, Stats& st) {
+RT_DEV ShadeOut shade_begin(const DeviceScene& sc, uint32_t kind, const DPrim& pr, V3 o, V3 d,
+                            double time, double t, const DrawKey& key, Stats& st) {
   ShadeOut out;
   out.attenuation = v3(0.0, 0.0, 0.0);
   out.direction = v3(0.0, 0.0, 0.0);
   out.emitted = v3(0.0, 0.0, 0.0);
+  out.fuzz = 0.0;
+  out.kind = kind;
   out.scattered = false;
   out.emits = false;
+  out.needs_vector = false;
   stat<STATS>(st, RT_STAT_SHADE_LAMBERTIAN + (int)kind);
   const DMaterial m = sc.materials[pr.material];
   const bool textured = kind == RT_MAT_LAMBERTIAN || kind == RT_MAT_DIFFUSE_LIGHT ||
@@ -238,16 +246,17 @@ RT_DEV ShadeOut shade_hit(const DeviceScene& sc, uint32_t kind, const DPrim& pr,
   Record rec = make_record<!SOLID>(sc, pr, o, d, time, t, want_uv);
   out.p = rec.p;
   if (kind == RT_MAT_LAMBERTIAN) {  // lambertian.rs:13-25
-    V3 dir = vadd(rec.normal, rand_unit_vector(key, &st));
-    if (vnear_zero(dir)) dir = rec.normal;
-    out.direction = dir;
+    out.direction = rec.normal;
     out.attenuation = texture_value<STATS, SOLID>(sc, m.texture, rec.u, rec.v, rec.p, st);
     out.scattered = true;
+    out.needs_vector = true;
   } else if (kind == RT_MAT_METAL) {  // metal.rs:12-28
     V3 reflected = vreflect(vunit(d), rec.normal);
     if (vdot(reflected, rec.normal) > 0.0) {
-      out.direction = vadd(reflected, vscale(rand_unit_vector(key, &st), m.param));
+      out.direction = reflected;
+      out.fuzz = m.param;
       out.scattered = true;
+      out.needs_vector = true;
     }
     out.attenuation = v3(m.albedo);
   } else if (kind == RT_MAT_DIELECTRIC) {  // dielectric.rs:14-38
@@ -267,10 +276,25 @@ RT_DEV ShadeOut shade_hit(const DeviceScene& sc, uint32_t kind, const DPrim& pr,
     out.emits = true;
   } else {  // isotropic.rs:10-17
     out.attenuation = texture_value<STATS, SOLID>(sc, m.texture, rec.u, rec.v, rec.p, st);
-    out.direction = rand_unit_vector(key, &st);
     out.scattered = true;
+    out.needs_vector = true;
   }
   return out;
+}
+
+// Second half: `inside` is the accepted candidate of rand_unit_vector's rejection loop.
+RT_DEV void shade_finish(ShadeOut& out, V3 inside) {
+  if (!out.needs_vector) return;
+  const V3 ruv = vunit(inside);
+  if (out.kind == RT_MAT_LAMBERTIAN) {
+    V3 dir = vadd(out.direction, ruv);
+    if (vnear_zero(dir)) dir = out.direction;
+    out.direction = dir;
+  } else if (out.kind == RT_MAT_METAL) {
+    out.direction = vadd(out.direction, vscale(ruv, out.fuzz));
+  } else {
+    out.direction = ruv;
+  }
 }
 
 // One instantiation per bin (BIN 0 = misses, BIN 1 + k = material kind k), each
@@ -284,6 +308,11 @@ shade_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps, uint32_t bounce, uint3
   __shared__ uint32_t s_next[kStageCap];
   __shared__ uint32_t s_next_count;
   __shared__ uint32_t s_word;
+  __shared__ uint32_t s_xch[(kBlock / 64) * 128];
+  lds_u32* xch = (lds_u32*)s_xch + (threadIdx.x / 64u) * 128u;
+  // material kinds whose scatter draws a random unit vector
+  constexpr bool kVector = BIN == 1 + RT_MAT_LAMBERTIAN || BIN == 1 + RT_MAT_METAL ||
+                           BIN == 1 + RT_MAT_ISOTROPIC;
   uint32_t* counters = pb.counters + (size_t)bounce * kCounterStride;
   uint32_t* next_live = pb.live[(bounce + 1u) & 1u];
   const uint32_t total = counters[BIN];
@@ -299,6 +328,9 @@ shade_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps, uint32_t bounce, uint3
     bool valid = i < total;
     bool survives = false;
     uint32_t path = 0;
+    DrawKey key{ps.seed, 0u, 0u, bounce};
+    ShadeOut so;
+    so.needs_vector = false;
     if (valid) {
       path = queue[i];
       double4 bt = pb.beta[path];
@@ -315,24 +347,31 @@ shade_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps, uint32_t bounce, uint3
         const DPrim pr = sc.prims[pb.hit_item[path]];
         uint32_t s_local = path / ps.n_pixels, local = path % ps.n_pixels;
         uint32_t x = ps.x0 + local % ps.ww, y = ps.y0 + local / ps.ww;
-        DrawKey key{ps.seed, y * ps.width + x, ps.sample_base + s_local, bounce};
-        ShadeOut so = shade_hit<STATS, SOLID>(sc, (uint32_t)BIN - 1u, pr, v3(ro.x, ro.y, ro.z),
-                                              v3(rdv.x, rdv.y, rdv.z), ro.w, rdv.w, key, st);
+        key.pixel = y * ps.width + x;
+        key.sample = ps.sample_base + s_local;
+        so = shade_begin<STATS, SOLID>(sc, (uint32_t)BIN - 1u, pr, v3(ro.x, ro.y, ro.z),
+                                       v3(rdv.x, rdv.y, rdv.z), ro.w, rdv.w, key, st);
         if (so.emits) {
           double4 L = pb.radiance[path];
           V3 add = vmul(beta, so.emitted);
           pb.radiance[path] = make_double4(L.x + add.x, L.y + add.y, L.z + add.z, 0.0);
         }
         // depth budget: the scattered ray of the last allowed hit returns black (main.rs:121-122)
-        if (so.scattered && bounce + 1u < max_depth) {
-          survives = true;
+        survives = so.scattered && bounce + 1u < max_depth;
+        if (survives) {
+          // everything but the direction is known before the random vector
           V3 nb = vmul(beta, so.attenuation);
           pb.beta[path] = make_double4(nb.x, nb.y, nb.z, 0.0);
           pb.ray_o[path] = make_double4(so.p.x, so.p.y, so.p.z, ro.w);
-          pb.ray_d[path] = make_double4(so.direction.x, so.direction.y, so.direction.z, 0.0);
         }
       }
     }
+    if (kVector) {  // whole waves: the lanes look for their random vectors together
+      V3 inside = wave_rand_in_unit_sphere(survives && so.needs_vector, key, xch, 64u, st);
+      shade_finish(so, inside);
+    }
+    if (survives)
+      pb.ray_d[path] = make_double4(so.direction.x, so.direction.y, so.direction.z, 0.0);
     if (BIN != 0 && BIN != 1 + RT_MAT_DIFFUSE_LIGHT) {  // misses and lights end their paths
       uint32_t slot = stage_append(&s_next_count, survives);
       if (survives) s_next[slot] = path;
@@ -363,14 +402,6 @@ shade_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps, uint32_t bounce, uint3
 const uint32_t kWaveFlushAt = 128;
 const uint32_t kWaveStage = kWaveFlushAt + 64;
 
-// LDS writes of one wave are visible to its own later reads once they have been
-// issued in order; this keeps the compiler from moving accesses across.
-RT_DEV void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 RT_DEV void wave_flush(const uint32_t* stage, uint32_t n, uint32_t* g_counter, uint32_t* g_queue) {
   wave_lds_sync();
   uint32_t base = 0;
@@ -381,7 +412,7 @@ RT_DEV void wave_flush(const uint32_t* stage, uint32_t n, uint32_t* g_counter, u
 }
 
 template <int BLOCK, bool STATS, bool MEDIA>
-__global__ void __launch_bounds__(BLOCK)
+__global__ void __launch_bounds__(BLOCK, 4)  // registers for four waves per SIMD
 trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_t bounce,
              uint32_t max_depth, unsigned long long* g_stats) {
   extern __shared__ __align__(16) char smem[];
@@ -405,29 +436,36 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
     bool valid = i < n_live;
     bool survives = false;
     uint32_t path = 0;
+    DrawKey key{ps.seed, 0u, 0u, bounce};
+    ShadeOut so;
+    so.needs_vector = false;
     if (valid) {
       path = bounce == 0 ? i : live[i];
       uint32_t s_local = path / ps.n_pixels, local = path % ps.n_pixels;
       uint32_t x = ps.x0 + local % ps.ww, y = ps.y0 + local / ps.ww;
-      DrawKey key{ps.seed, y * ps.width + x, ps.sample_base + s_local, bounce};
+      key.pixel = y * ps.width + x;
+      key.sample = ps.sample_base + s_local;
       V3 o, d;
       double time;
-      // the first bounce makes its own camera ray and starts from beta = 1, L = 0
-      V3 beta = v3(1.0, 1.0, 1.0);
+      // the first bounce makes its own camera ray
       if (bounce == 0) {
         camera_ray(sc, ps, x, y, key, o, d, time);
       } else {
         double4 ro = pb.ray_o[path];
         double4 rdv = pb.ray_d[path];
-        double4 bt = pb.beta[path];
         o = v3(ro.x, ro.y, ro.z);
         d = v3(rdv.x, rdv.y, rdv.z);
         time = ro.w;
-        beta = v3(bt.x, bt.y, bt.z);
       }
       stat<STATS>(st, RT_STAT_RAYS);
       RT_LP(st, LP_RAY);
       Closest h = closest_hit<STATS, MEDIA>(sc, lds, o, d, time, 0.001, key, st);
+      // ... and starts from beta = 1, L = 0
+      V3 beta = v3(1.0, 1.0, 1.0);
+      if (bounce != 0) {
+        double4 bt = pb.beta[path];
+        beta = v3(bt.x, bt.y, bt.z);
+      }
       V3 add = v3(0.0, 0.0, 0.0);
       bool adds = false;
       if (h.item == kNoPrim) {
@@ -439,17 +477,18 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
         stat<STATS>(st, RT_STAT_HITS);
         RT_LP(st, LP_SHADE);
         const DPrim pr = load_prim(sc, lds, h.item);
-        ShadeOut so = shade_hit<STATS, true>(sc, (h.kind >> 8) & 7u, pr, o, d, time, h.t, key, st);
+        so = shade_begin<STATS, true>(sc, (h.kind >> 8) & 7u, pr, o, d, time, h.t, key, st);
         if (so.emits) {
           add = vmul(beta, so.emitted);
           adds = true;
         }
-        if (so.scattered && bounce + 1u < max_depth) {
-          survives = true;
+        // depth budget: the scattered ray of the last allowed hit returns black (main.rs:121-122)
+        survives = so.scattered && bounce + 1u < max_depth;
+        if (survives) {
+          // everything but the direction is known before the random vector
           V3 nb = vmul(beta, so.attenuation);
           pb.beta[path] = make_double4(nb.x, nb.y, nb.z, 0.0);
           pb.ray_o[path] = make_double4(so.p.x, so.p.y, so.p.z, time);
-          pb.ray_d[path] = make_double4(so.direction.x, so.direction.y, so.direction.z, 0.0);
         }
       }
       // L += add; the first bounce also starts every path's L
@@ -460,6 +499,14 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
         pb.radiance[path] = make_double4(L.x + add.x, L.y + add.y, L.z + add.z, 0.0);
       }
     }
+    {  // whole waves: the lanes look for their random vectors together
+      // (the wave's part of the first two stack rows is idle between traversals)
+      V3 inside = wave_rand_in_unit_sphere(survives && so.needs_vector, key,
+                                           lds.stack - (threadIdx.x & 63u), BLOCK, st);
+      shade_finish(so, inside);
+    }
+    if (survives)
+      pb.ray_d[path] = make_double4(so.direction.x, so.direction.y, so.direction.z, 0.0);
     const unsigned long long mask = __ballot(survives);
     if (survives)
       stage[n_staged + (uint32_t)__popcll(mask & ((1ull << lane_id()) - 1ull))] = path;
@@ -711,7 +758,9 @@ uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); 
 // leaf slots with what is left.
 LdsLayout plan_lds(const FlatScene& f, uint32_t block, uint32_t budget) {
   LdsLayout l{};
-  l.stack_depth = f.stack_entries + 1u;  // one spare: a visit stores before it knows whether it keeps
+  // one spare: a visit stores before it knows whether it keeps; two rows at least: they double as
+  // the exchange area of wave_rand_in_unit_sphere
+  l.stack_depth = std::max(f.stack_entries + 1u, 2u);
   l.entry_bits = entry_code_bits((uint32_t)f.nodes.size(), (uint32_t)f.items.size());
   uint32_t used = l.stack_depth * block * (uint32_t)sizeof(uint32_t);
   budget = std::max(budget, used + 4096u);  // leave room for a few records
@@ -927,6 +976,8 @@ int rt_create(const rt_config* cfg, rt_ctx** out) {
   ctx->n_cus = (uint32_t)prop.multiProcessorCount;
   if (cfg && cfg->max_paths_in_flight) {
     ctx->max_paths = cfg->max_paths_in_flight;
+  } else if (const char* e = getenv("MI355RT_MAX_PATHS")) {
+    ctx->max_paths = std::max<uint64_t>(strtoull(e, nullptr, 10), 1u << 16);
   } else {
     // default: a quarter of the free device memory at ~160 bytes of state per path,
     // between 2^22 and 2^27 paths (fewer, larger passes spend less time in their tails)

@@ -78,7 +78,10 @@ struct DrawKey {
 RT_DEV u32x4 draw(const DrawKey& k, uint32_t purpose, uint32_t seq) {
   return draw_block(k.seed, k.pixel, k.sample, k.bounce, purpose, seq);
 }
-const uint32_t kMaxRejections = 4096;  // the loop ends with probability 1 - 2^-4000 long before
+#ifndef RT_MAX_REJECTIONS
+#define RT_MAX_REJECTIONS 4096
+#endif
+const uint32_t kMaxRejections = RT_MAX_REJECTIONS;  // the loop ends with probability 1 - 2^-4000 long before
 
 #ifdef RT_LANE_PROFILE
 struct Stats;
@@ -391,17 +394,23 @@ RT_DEV Record make_record(const DeviceScene& sc, const DPrim& pr, V3 o, V3 d, do
 //
 // The test only culls, so it runs in f32 with FMA; what makes it safe is that it
 // is CONSERVATIVE against the exact slab parameters T = (b - o) / d:
-//   inv = fl(1 / fl32(d)) carries a relative error < 2^-22, the final FMA another
-//   2^-24: both scale T and are absorbed by comparing t0 <= t1 * (1 + 2^-18);
+//   inv = fl(1 / fl32(d)) carries a relative error < 2^-22, each FMA another
+//   2^-24: both scale T and are absorbed by widening the exit side by 1 + 2^-18;
 //   rounding o to f32 and rounding -o*inv shift T by at most 2^-23 |o inv|: the
 //   pad E = 2^-21 |o inv| is subtracted on the entry side and added on the exit
 //   side (which plane is which follows the sign of inv).
+// The widening is folded into the constants: the plane that is the exit for this
+// direction sign gets (inv, -o*inv) both multiplied by 1 + 2^-18 (two more
+// roundings of 2^-24 each, inside the same budgets), so a box test is
+//   t_lo = fma(lo, inv_lo, add_lo), t_hi = fma(hi, inv_hi, add_hi),
+//   max(min(t_lo, t_hi) per axis, tmin) <= min(max(t_lo, t_hi) per axis, best * (1 + 2^-18)).
 // A zero or denormal d would give inv = inf and inf - inf = NaN; inv is clamped
 // to +-1e25, which still puts both planes beyond every real t.
 // Every operation is a correctly rounded IEEE f32 operation, so a CPU can
 // reproduce the decisions bit for bit.
+const float kWiden = 1.000003814697265625f;  // 1 + 2^-18
 struct CullAxis {
-  float inv, noi_lo, noi_hi;
+  float inv_lo, add_lo, inv_hi, add_hi;
 };
 RT_DEV CullAxis cull_axis(double o, double d) {
   float d32 = (float)d, o32 = (float)o;
@@ -410,9 +419,17 @@ RT_DEV CullAxis cull_axis(double o, double d) {
   float noi = -(o32 * inv);
   float e = fabsf(noi) * 4.76837158203125e-07f;  // 2^-21
   CullAxis c;
-  c.inv = inv;
-  c.noi_lo = inv >= 0.0f ? noi - e : noi + e;
-  c.noi_hi = inv >= 0.0f ? noi + e : noi - e;
+  if (inv >= 0.0f) {  // lo plane is the entry, hi plane the exit
+    c.inv_lo = inv;
+    c.add_lo = noi - e;
+    c.inv_hi = inv * kWiden;
+    c.add_hi = (noi + e) * kWiden;
+  } else {
+    c.inv_lo = inv * kWiden;
+    c.add_lo = (noi + e) * kWiden;
+    c.inv_hi = inv;
+    c.add_hi = noi - e;
+  }
   return c;
 }
 
@@ -469,6 +486,67 @@ RT_DEV LdsScene lds_stage(const DeviceScene& sc, const LdsLayout& lay, char* sme
   return l;
 }
 
+// LDS writes of one wave are visible to its own later reads once they have been
+// issued in order; this keeps the compiler from moving accesses across.
+RT_DEV void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// The accepted candidate of rand_unit_vector's rejection loop (vec3.rs:35-47, before
+// the normalisation) for every lane with `need`, found by the whole wave together.
+//
+// A lane on its own repeats "draw candidate `it`, stop at the first one inside the
+// unit sphere"; the wave then runs as many trips as its unluckiest lane while most
+// lanes sit idle.  Here the n lanes still looking share all 64 lanes: each owner
+// gets c = 2^k <= 64/n helpers, helper j of an owner tries that owner's candidate
+// number tried + j (the owner's key travels through two rows of 64 words of LDS
+// private to the wave, `xch` and `xch + row`: callers lend rows of the idle
+// traversal stack), and the owner takes the accepted candidate with the lowest number.
+// The candidates, their order and therefore the result are exactly the lone
+// lane's; only who evaluates them changes.  Must be called by all 64 lanes.
+RT_DEV V3 wave_rand_in_unit_sphere(bool need, const DrawKey& key, lds_u32* xch, uint32_t row,
+                                   Stats& st) {
+  const uint32_t lane = __lane_id();
+  unsigned long long pending = __ballot(need);
+  uint32_t tried = 0;
+  V3 v = v3(0.0, 0.0, 0.0);
+  while (pending != 0ull) {
+    RT_LP(st, LP_REJECT);
+    const uint32_t n = (uint32_t)__popcll(pending);
+    const uint32_t c_log = n == 1u ? 6u : (uint32_t)__clz((int)(n - 1u)) - 26u;
+    const bool mine = (pending >> lane) & 1ull;
+    const uint32_t rank = (uint32_t)__popcll(pending & ((1ull << lane) - 1ull));
+    if (mine) {
+      xch[rank] = key.pixel;
+      xch[row + rank] = key.sample;
+    }
+    wave_lds_sync();
+    const uint32_t q = lane >> c_log, sub = lane & ((1u << c_log) - 1u);
+    const bool active = q < n;
+    const uint32_t qq = active ? q : 0u;
+    const uint32_t seq = tried + sub;
+    double x, y, z;
+    sym3_42(draw_block(key.seed, xch[qq], xch[row + qq], key.bounce, DRAW_SCATTER, seq), x, y, z);
+    // the lone loop gives up after kMaxRejections candidates and keeps the last one
+    const bool ok = active && seq < kMaxRejections &&
+                    (x * x + y * y + z * z < 1.0 || seq == kMaxRejections - 1u);
+    const unsigned long long accepted = __ballot(ok);
+    const uint32_t shift = rank << c_log;
+    const unsigned long long group = c_log == 6u ? ~0ull : ((1ull << (1u << c_log)) - 1ull);
+    const unsigned long long m = mine ? ((accepted >> shift) & group) : 0ull;
+    const bool got = m != 0ull;
+    const int src = got ? (int)(shift + (uint32_t)__ffsll((long long)m) - 1u) : (int)lane;
+    const double fx = __shfl(x, src), fy = __shfl(y, src), fz = __shfl(z, src);
+    if (got) v = v3(fx, fy, fz);
+    pending &= ~__ballot(got);
+    tried += 1u << c_log;
+    wave_lds_sync();
+  }
+  return v;
+}
+
 RT_DEV DPrim load_prim(const DeviceScene& sc, const LdsScene& lds, uint32_t slot) {
   union {
     f32x4 q[4];
@@ -503,7 +581,6 @@ RT_DEV DPrim load_prim(const DeviceScene& sc, const LdsScene& lds, uint32_t slot
 // Primitive tests always use the reference's full range tmin..inf so that equal
 // t can be resolved by rank.
 const uint32_t kNoEntry = 0xFFFFFFFFu;
-const float kWiden = 1.000003814697265625f;  // 1 + 2^-18, see cull_axis
 
 RT_HD uint32_t make_entry(uint32_t a, uint32_t b) {
   return (b & 0x80000000u) ? (((a << 2) | (b & 3u)) << 1) : ((((a << 3) | (b - 1u)) << 1) | 1u);
@@ -541,7 +618,12 @@ RT_DEV Closest closest_hit(const DeviceScene& sc, const LdsScene& lds, V3 o, V3 
   // culling arithmetic: once per ray, then one FMA per slab plane
   const CullAxis cx = cull_axis(o.x, d.x), cy = cull_axis(o.y, d.y), cz = cull_axis(o.z, d.z);
   const float tmin32 = (float)tmin * 0.99f;
-  float best32 = __int_as_float(0x7F800000);
+  float best32w = __int_as_float(0x7F800000);  // best t so far, times kWiden
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  // constants paired the way the record's words pair up: (lo.x lo.y) (lo.z hi.x) (hi.y hi.z)
+  const f32x2 mul_a = {cx.inv_lo, cy.inv_lo}, add_a = {cx.add_lo, cy.add_lo};
+  const f32x2 mul_b = {cz.inv_lo, cx.inv_hi}, add_b = {cz.add_lo, cx.add_hi};
+  const f32x2 mul_c = {cy.inv_hi, cz.inv_hi}, add_c = {cy.add_hi, cz.add_hi};
   const double dd = vlen2(d);
   const f32x4* gnodes = (const f32x4*)sc.nodes;
   uint32_t sp = 0;
@@ -552,7 +634,7 @@ RT_DEV Closest closest_hit(const DeviceScene& sc, const LdsScene& lds, V3 o, V3 
     while (sp) {
       RT_LP(st, LP_POP);
       uint32_t w = stack[(--sp) * stride];
-      if (__uint_as_float((w >> ebits) << (ebits - 1u)) <= best32 * kWiden) return w & emask;
+      if (__uint_as_float((w >> ebits) << (ebits - 1u)) <= best32w) return w & emask;
     }
     return kNoEntry;
   };
@@ -582,13 +664,15 @@ RT_DEV Closest closest_hit(const DeviceScene& sc, const LdsScene& lds, V3 o, V3 
 #pragma unroll
       for (uint32_t k = 0; k < 4; ++k) {
         const f32x4 n0 = r[2 * k], n1 = r[2 * k + 1];
-        float ax = fmaf(n0.x, cx.inv, cx.noi_lo), bx = fmaf(n0.w, cx.inv, cx.noi_hi);
-        float ay = fmaf(n0.y, cy.inv, cy.noi_lo), by = fmaf(n1.x, cy.inv, cy.noi_hi);
-        float az = fmaf(n0.z, cz.inv, cz.noi_lo), bz = fmaf(n1.y, cz.inv, cz.noi_hi);
+        // three packed FMAs: (ax ay) (az bx) (by bz)
+        const f32x2 pa = __builtin_elementwise_fma(f32x2{n0.x, n0.y}, mul_a, add_a);
+        const f32x2 pb = __builtin_elementwise_fma(f32x2{n0.z, n0.w}, mul_b, add_b);
+        const f32x2 pc = __builtin_elementwise_fma(f32x2{n1.x, n1.y}, mul_c, add_c);
+        const float ax = pa.x, ay = pa.y, az = pb.x, bx = pb.y, by = pc.x, bz = pc.y;
         float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin32));
-        float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best32));
+        float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best32w));
         const uint32_t word = ((__float_as_uint(t0) >> (ebits - 1u)) << ebits) | __float_as_uint(n1.z);
-        w[k] = (k < n && t0 <= t1 * kWiden) ? word : kNoEntry;
+        w[k] = (k < n && t0 <= t1) ? word : kNoEntry;
       }
       // sort ascending (five compare-exchanges)
       {
@@ -630,7 +714,7 @@ RT_DEV Closest closest_hit(const DeviceScene& sc, const LdsScene& lds, V3 o, V3 
           best.t = t;
           best.item = slot;
           best.kind = pr.kind;
-          best32 = (float)t;
+          best32w = (float)t * kWiden;
         }
       }
     }

@@ -22,8 +22,11 @@ scene = HostScene.load_frozen(os.path.join(ROOT, "tests", "golden", name + ".rts
 scene.set_image(w, h)
 ref = None
 for combo in itertools.product(*values) if values else [()]:
+    flags = 0
     for k, v in zip(keys, combo):
-        if v == "-":
+        if k == "FLAGS":  # render flags (4 = force the binned extend/shade pipeline), not an env var
+            flags = int(v)
+        elif v == "-":
             os.environ.pop(k, None)
         else:
             os.environ[k] = v
@@ -31,7 +34,7 @@ for combo in itertools.product(*values) if values else [()]:
     ctx.upload(scene)
     best = 1e9
     for rep in range(3):
-        p = ctx.params(w, h, 0, spp, scene.max_depth, seed=1)
+        p = ctx.params(w, h, 0, spp, scene.max_depth, seed=1, flags=flags)
         t0 = time.perf_counter()
         img, st = ctx.render(p, dtype=np.float32, timing=True)
         best = min(best, time.perf_counter() - t0)
