@@ -83,23 +83,7 @@ RT_DEV u32x4 draw(const DrawKey& k, uint32_t purpose, uint32_t seq) {
 #endif
 const uint32_t kMaxRejections = RT_MAX_REJECTIONS;  // the loop ends with probability 1 - 2^-4000 long before
 
-#ifdef RT_LANE_PROFILE
-struct Stats;
-RT_DEV void reject_trip(Stats* st);
-#define RT_LP_REJECT(st) reject_trip(st)
-#else
-#define RT_LP_REJECT(st) ((void)0)
-#endif
-struct Stats;
-RT_DEV V3 rand_unit_vector(const DrawKey& k, Stats* st = nullptr) {  // vec3.rs:35-47
-  V3 v = v3(0.0, 0.0, 0.0);
-  for (uint32_t it = 0; it < kMaxRejections; ++it) {
-    RT_LP_REJECT(st);
-    sym3_42(draw(k, DRAW_SCATTER, it), v.x, v.y, v.z);
-    if (vlen2(v) < 1.0) break;
-  }
-  return vunit(v);
-}
+// (rand_unit_vector, vec3.rs:35-47, is wave_rand_in_unit_sphere + shade_finish below)
 RT_DEV V3 rand_in_unit_disk(const DrawKey& k) {  // vec3.rs:49-60
   V3 v = v3(0.0, 0.0, 0.0);
   for (uint32_t it = 0; it < kMaxRejections; ++it) {
@@ -138,9 +122,6 @@ RT_DEV void lane_trip(Stats& st, int loop) {
   if ((int)__lane_id() == __ffsll((long long)m) - 1) st.trips[2 * loop + 1]++;
 }
 #define RT_LP(st, loop) lane_trip(st, loop)
-RT_DEV void reject_trip(Stats* st) {
-  if (st) lane_trip(*st, LP_REJECT);
-}
 #else
 #define RT_LP(st, loop) ((void)0)
 #endif
