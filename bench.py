@@ -199,6 +199,13 @@ def main():
             "sphere_tests_per_ray": float(st[abi.STAT_NAMES.index("sphere_tests")]) / rays,
             "grays_per_s": rays * args.steps / elapsed / 1e9,
         }
+        # HBM bytes per launch come from separate rocprofv3 counter passes over the same kernel and
+        # pass size (committed next to the kernel-trace summary); the counters cannot run in here
+        tpath = os.path.join(ROOT, "profiles", "r01_trace_kernel_hbm_traffic.json")
+        if fused and os.path.exists(tpath) and (args.width, args.height) == (WIDTH, HEIGHT) and args.spp >= 64:
+            with open(tpath) as f:
+                result["roofline"]["traffic"] = json.load(f)["hbm_bytes_per_launch"]
+            result["roofline"]["traffic_unit"] = "bytes per launch (HBM, PMC passes at 64 spp per pass)"
         if not args.no_cpu:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import pyoracle as po
