@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <functional>
 #include <cstdint>
 #include <cstring>
 #include <limits>
@@ -842,6 +843,12 @@ struct SceneData {
   std::vector<std::unique_ptr<Hittable>> prim_items;
   std::vector<std::unique_ptr<Hittable>> object_items;
   std::vector<uint32_t> prim_owner;
+  // flat traversal only: the reference hierarchy's boxes from the root down to the leaf list
+  // of every object, and which items answer to them (sides of a Cuboid that reach outside
+  // Cuboid::bounding_box: the Y sides when size.x != size.z, cuboid.rs:21-30 and :45-47)
+  std::vector<std::vector<Aabb>> chains;
+  std::vector<uint32_t> chain_of_object;
+  std::vector<uint8_t> prim_answers_to_chain, object_answers_to_chain;
   Camera camera;
   Color background;
   std::vector<uint8_t> texels;
@@ -999,6 +1006,38 @@ SceneData* build_scene(const rt_scene& s) {
   }
   // BvhNode::new(camera.shutter_time, hittables) (src/scene/loader.rs:86)
   d->world = BvhNode::build(Range{c.time0, c.time1}, std::move(entries), 0);
+
+  // box chains of the reference hierarchy, for the flat traversal
+  d->chain_of_object.assign(s.n_objects, 0);
+  {
+    std::vector<Aabb> path;
+    std::function<void(const BvhNode&)> walk = [&](const BvhNode& n) {
+      bool pushed = n.bbox.some;
+      if (pushed) path.push_back(n.bbox.box);
+      if (n.leaf) {
+        for (uint32_t id : n.list.ids) d->chain_of_object[id] = (uint32_t)d->chains.size();
+        d->chains.push_back(path);
+      } else {
+        walk(*n.right);
+        walk(*n.left);
+      }
+      if (pushed) path.pop_back();
+    };
+    walk(*d->world);
+  }
+  d->prim_answers_to_chain.assign(s.n_prims, 0);
+  d->object_answers_to_chain.assign(s.n_objects, 0);
+  for (uint32_t i = 0; i < s.n_objects; ++i) {
+    const rt_object& o = s.objects[i];
+    if (!o.is_cuboid || o.cuboid_half[0] == o.cuboid_half[2]) continue;
+    if (o.is_medium) {
+      d->object_answers_to_chain[i] = 1;
+    } else {
+      for (uint32_t k = 0; k < o.prim_count; ++k)
+        if (s.prims[o.first_prim + k].kind == RT_PRIM_RECT && s.prims[o.first_prim + k].axis == 1)
+          d->prim_answers_to_chain[o.first_prim + k] = 1;
+    }
+  }
 
   // per-item hittables for the flat traversal
   d->prim_items.resize(s.n_prims);
@@ -1170,6 +1209,15 @@ OptHit flat_hit(const SceneData& sc, const FlatBvh& bvh, const Ray& ray, Range t
         if (!h) continue;
         OptHit r = h->hit(ray, t_range, cx);
         if (!r.some) continue;
+        // geometry outside its object's box: the reference finds it only through its own boxes
+        bool answers = it.prim == 0xFFFFFFFFu ? sc.object_answers_to_chain[it.object]
+                                              : sc.prim_answers_to_chain[it.prim];
+        if (answers) {
+          bool pass = true;
+          for (const Aabb& b : sc.chains[sc.chain_of_object[it.object]])
+            pass = pass && b.intersect(ray, t_range);
+          if (!pass) continue;
+        }
         r.rec.object = it.object;
         if (!best.some || r.rec.t < best.rec.t || (r.rec.t == best.rec.t && it.rank < best_rank)) {
           best = r;

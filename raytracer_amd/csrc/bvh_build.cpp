@@ -177,6 +177,51 @@ void reference_order(const std::vector<Box>& boxes, std::vector<uint32_t>& ids, 
   reference_order(boxes, left, next, out);
 }
 
+// The box chains of the reference's hierarchy (bvh.rs:33-77): one chain per leaf list, the
+// boxes of the nodes from the root down to it.  A node's box is the union of its objects'
+// boxes (Aabb::surrounding is exact, so unions of unions are the same numbers).
+struct RefChains {
+  std::vector<double> boxes;            // 6 per box
+  std::vector<uint32_t> ranges;         // first, count per chain
+  std::vector<uint32_t> chain_of_object;
+};
+void reference_chains(const std::vector<Box>& boxes, std::vector<uint32_t>& ids, int axis,
+                      std::vector<Box>& path, RefChains& out) {
+  const size_t kMaxPerLeaf = 256;  // bvh.rs:9
+  Box all;
+  for (uint32_t id : ids) all.grow(boxes[id]);
+  path.push_back(all);
+  if (ids.size() < kMaxPerLeaf) {
+    uint32_t chain = (uint32_t)(out.ranges.size() / 2);
+    out.ranges.push_back((uint32_t)(out.boxes.size() / 6));
+    out.ranges.push_back((uint32_t)path.size());
+    for (const Box& b : path) {
+      for (int a = 0; a < 3; ++a) out.boxes.push_back(b.lo[a]);
+      for (int a = 0; a < 3; ++a) out.boxes.push_back(b.hi[a]);
+    }
+    for (uint32_t id : ids) out.chain_of_object[id] = chain;
+  } else {
+    std::stable_sort(ids.begin(), ids.end(), [&](uint32_t a, uint32_t b) {
+      double ka = (boxes[a].lo[axis] + boxes[a].hi[axis]) / 2.0;
+      double kb = (boxes[b].lo[axis] + boxes[b].hi[axis]) / 2.0;
+      return of_less(ka, kb);
+    });
+    size_t half = ids.size() / 2;
+    std::vector<uint32_t> left(ids.begin(), ids.begin() + (long)half);
+    std::vector<uint32_t> right(ids.begin() + (long)half, ids.end());
+    int next = (axis + 1) % 3;
+    reference_chains(boxes, right, next, path, out);
+    reference_chains(boxes, left, next, path, out);
+  }
+  path.pop_back();
+}
+
+// Does a side of this cuboid reach outside Cuboid::bounding_box?  The Y sides take
+// size.z along x and size.x along z (cuboid.rs:21-30 with rect.rs:27-31).
+bool cuboid_overhangs(const rt_object& o) {
+  return o.is_cuboid && o.cuboid_half[0] != o.cuboid_half[2];
+}
+
 // ---- true (conservative) boxes for the device hierarchy ---------------------
 
 Box true_prim_box(const rt_prim& p, double t0, double t1) {
@@ -503,6 +548,22 @@ std::string flatten_scene(const rt_scene& s, FlatScene& out, int& code) {
     }
   }
 
+  // box chains of the reference's hierarchy, only for scenes that need them
+  RefChains chains;
+  {
+    bool any = false;
+    for (uint32_t i = 0; i < s.n_objects && !any; ++i) any = cuboid_overhangs(s.objects[i]);
+    if (any) {
+      chains.chain_of_object.assign(s.n_objects, 0);
+      std::vector<uint32_t> all(s.n_objects);
+      std::iota(all.begin(), all.end(), 0u);
+      std::vector<Box> path;
+      reference_chains(ref_boxes, all, 0, path, chains);
+      out.chain_boxes = chains.boxes;
+      out.chain_ranges = chains.ranges;
+    }
+  }
+
   auto make_record = [&](const rt_prim& p, uint32_t ops_word, uint32_t object) {
     DPrim d{};
     const rt_material& m = s.materials[p.material];
@@ -534,6 +595,11 @@ std::string flatten_scene(const rt_scene& s, FlatScene& out, int& code) {
       d.p[2] = b.hi[d1];
       d.p[3] = b.lo[d2];
       d.p[4] = b.hi[d2];
+      const rt_object& o = s.objects[object];
+      if (!o.is_medium && p.axis == 1 && cuboid_overhangs(o)) {
+        d.kind |= kChainBit;
+        d.p[5] = (double)chains.chain_of_object[object];
+      }
     }
     d.kind |= (m.kind & 7u) << 8;
     d.kind |= needs_uv << 11;
@@ -562,6 +628,10 @@ std::string flatten_scene(const rt_scene& s, FlatScene& out, int& code) {
       d.p[0] = o.neg_inv_density;
       d.p[1] = (double)out.boundary.size();
       d.p[2] = (double)o.prim_count;
+      if (cuboid_overhangs(o)) {  // the medium as a whole answers to its object's chain
+        d.kind |= kChainBit;
+        d.p[3] = (double)chains.chain_of_object[oi];
+      }
       Box b;
       for (uint32_t k = 0; k < o.prim_count; ++k) {
         const rt_prim& p = s.prims[o.first_prim + k];

@@ -20,13 +20,15 @@ enum DPrimKind : uint32_t {
 
 // 64-byte primitive record.
 //   kind word: bits 0-3 DPrimKind, bits 4-5 rect axis, bits 8-10 material kind
-//              (rt_material_kind) of `material`, bit 11 "texture needs (u,v)".
+//              (rt_material_kind) of `material`, bit 11 "texture needs (u,v)",
+//              bit 12 "a hit counts only if the ray passes the reference's box chain"
+//              (a cuboid side that sticks out of Cuboid::bounding_box, see FlatScene::chain_boxes).
 //   ops word : first op (low 24 bits) | op count (high 8 bits), outermost first.
 //   sphere        p = {cx, cy, cz, radius, -, -}
 //   moving sphere p = {c0x, c0y, c0z, radius, time0, aux index}; aux = {c1x, c1y, c1z, time1}
-//   rect          p = {center[axis], min[d1], max[d1], min[d2], max[d2], -}
+//   rect          p = {center[axis], min[d1], max[d1], min[d2], max[d2], chain (bit 12)}
 //                 (d1 = axis.next(), d2 = d1.next(); min/max as rect.rs:20-34 computes them)
-//   medium        p = {neg_inv_density, first boundary prim, boundary prim count, -, -, -}
+//   medium        p = {neg_inv_density, first boundary prim, boundary prim count, chain (bit 12), -, -}
 struct DPrim {
   double p[6];
   uint32_t kind;
@@ -75,6 +77,7 @@ const uint32_t kMaxBvhDepth = 32;      // levels of the binary tree the wide one
 const uint32_t kMaxStackEntries = 64;  // 8-byte traversal stack entries per lane that LDS can hold
 const uint32_t kMaxLeafItems = 8;     // upper bound; the builder's default is lower
 const uint32_t kNoPrim = 0xFFFFFFFFu;
+const uint32_t kChainBit = 1u << 12;
 
 // Everything the device needs, still in host memory.
 struct FlatScene {
@@ -90,6 +93,15 @@ struct FlatScene {
   std::vector<rt_perlin> perlin;
   std::vector<DImage> images;
   std::vector<uint8_t> texels;
+  // The reference's own hierarchy (bvh.rs:33-77) culls with Aabb::intersect at every node from
+  // the root to the leaf list an object sits in.  For geometry inside its object's
+  // bounding_box() that never removes a hit, so the device ignores it; the Y sides of a
+  // Cuboid with size.x != size.z reach outside Cuboid::bounding_box (cuboid.rs:21-30 and
+  // :45-47), and there the reference's result depends on those boxes.  Only when a scene has
+  // such sides: chain_boxes holds {min xyz, max xyz} per box, chain_ranges {first, count}
+  // per chain (root first), and the flagged records name their chain.
+  std::vector<double> chain_boxes;
+  std::vector<uint32_t> chain_ranges;
   rt_camera camera{};
   double background[3] = {0, 0, 0};
   uint32_t bvh_depth = 0;      // levels of the wide hierarchy

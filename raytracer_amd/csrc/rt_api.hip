@@ -569,6 +569,7 @@ to_float_kernel(const double* in, float* out, uint64_t n) {
 }
 
 // ------------------------------------------------------------ first hit
+template <bool CHAINS>
 __global__ void __launch_bounds__(kBlock)
 first_hit_kernel(DeviceScene sc, LdsLayout lay, PassInfo ps, uint32_t* id, double* t_out,
                  double* normal) {
@@ -588,7 +589,7 @@ first_hit_kernel(DeviceScene sc, LdsLayout lay, PassInfo ps, uint32_t* id, doubl
                 offset);
   DrawKey key{0, 0, 0, 0};
   Stats st;
-  Closest h = closest_hit<false, false>(sc, lds, origin, dir, c.time0, 0.001, key, st);
+  Closest h = closest_hit<false, false, CHAINS>(sc, lds, origin, dir, c.time0, 0.001, key, st);
   if (h.item == kNoPrim) {
     id[local] = 0xFFFFFFFFu;
     t_out[local] = 0.0;
@@ -645,6 +646,8 @@ struct rt_ctx {
   DeviceArray<rt_perlin> perlin;
   DeviceArray<DImage> images;
   DeviceArray<uint8_t> texels;
+  DeviceArray<double> chain_boxes;
+  DeviceArray<uint32_t> chain_ranges;
   // path buffers, grown on demand
   PathBuffers pb{};
   uint64_t pb_capacity = 0;
@@ -867,7 +870,8 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats) {
   uint32_t blocks_per_cu = 16u;
   if (const char* e = getenv("MI355RT_BLOCKS_PER_CU")) blocks_per_cu = (uint32_t)strtoul(e, nullptr, 10);
   const uint32_t max_grid = ctx->n_cus * std::max(1u, blocks_per_cu);
-  const bool media = ctx->flat.has_media;
+  // the MEDIA kernels carry the rare cases: constant media and records tied to the reference's box chain
+  const bool media = ctx->flat.has_media || !ctx->flat.chain_ranges.empty();
   bool solid = true;
   for (const DTexture& t : ctx->flat.textures) solid = solid && t.kind == RT_TEX_SOLID;
   // scenes whose shading is cheap run traversal and scatter fused; RT_FLAG_BINNED forces the
@@ -1032,6 +1036,8 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* scene) {
   if ((rc = upload(ctx, ctx->perlin, f.perlin)) != RT_OK) return rc;
   if ((rc = upload(ctx, ctx->images, f.images)) != RT_OK) return rc;
   if ((rc = upload(ctx, ctx->texels, f.texels)) != RT_OK) return rc;
+  if ((rc = upload(ctx, ctx->chain_boxes, f.chain_boxes)) != RT_OK) return rc;
+  if ((rc = upload(ctx, ctx->chain_ranges, f.chain_ranges)) != RT_OK) return rc;
   DeviceScene& ds = ctx->ds;
   ds.nodes = ctx->nodes.p;
   ds.prims = ctx->prims.p;
@@ -1044,6 +1050,8 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* scene) {
   ds.perlin = ctx->perlin.p;
   ds.images = ctx->images.p;
   ds.texels = ctx->texels.p;
+  ds.chain_boxes = ctx->chain_boxes.p;
+  ds.chain_ranges = ctx->chain_ranges.p;
   ds.n_nodes = (uint32_t)f.nodes.size();
   ds.has_media = f.has_media ? 1u : 0u;
   ds.root_code = f.nodes.empty() ? 1u : make_entry(f.nodes[0].a, f.nodes[0].b);
@@ -1089,7 +1097,8 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* scene) {
     RT_HIP(ctx, hipFuncSetAttribute((const void*)extend_kernel<false, true>, attr, bytes));
     RT_HIP(ctx, hipFuncSetAttribute((const void*)extend_kernel<true, false>, attr, bytes));
     RT_HIP(ctx, hipFuncSetAttribute((const void*)extend_kernel<true, true>, attr, bytes));
-    RT_HIP(ctx, hipFuncSetAttribute((const void*)first_hit_kernel, attr, bytes));
+    RT_HIP(ctx, hipFuncSetAttribute((const void*)first_hit_kernel<false>, attr, bytes));
+    RT_HIP(ctx, hipFuncSetAttribute((const void*)first_hit_kernel<true>, attr, bytes));
   }
   if (ctx->lds_trace.bytes > 32u * 1024u) {
     int bytes = (int)ctx->lds_trace.bytes;
@@ -1167,8 +1176,12 @@ int rt_first_hit(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_window* 
   if (e == hipSuccess) e = hipMalloc((void**)&d_t, n * sizeof(double));
   if (e == hipSuccess) e = hipMalloc((void**)&d_n, n * 3 * sizeof(double));
   if (e == hipSuccess) {
-    first_hit_kernel<<<blocks_for(n), kBlock, ctx->lds.bytes, ctx->stream>>>(ctx->ds, ctx->lds, ps, d_id,
-                                                                             d_t, d_n);
+    if (ctx->flat.chain_ranges.empty())
+      first_hit_kernel<false><<<blocks_for(n), kBlock, ctx->lds.bytes, ctx->stream>>>(ctx->ds, ctx->lds, ps,
+                                                                                      d_id, d_t, d_n);
+    else
+      first_hit_kernel<true><<<blocks_for(n), kBlock, ctx->lds.bytes, ctx->stream>>>(ctx->ds, ctx->lds, ps,
+                                                                                     d_id, d_t, d_n);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -1240,6 +1253,8 @@ void rt_destroy(rt_ctx* ctx) {
   ctx->perlin.release();
   ctx->images.release();
   ctx->texels.release();
+  ctx->chain_boxes.release();
+  ctx->chain_ranges.release();
   ctx->accum.release();
   ctx->stats.release();
   if (ctx->h_probe) (void)hipHostFree(ctx->h_probe);

@@ -28,6 +28,8 @@ struct DeviceScene {
   const rt_perlin* perlin;
   const DImage* images;
   const uint8_t* texels;
+  const double* chain_boxes;      // {min xyz, max xyz} per box of the reference's hierarchy
+  const uint32_t* chain_ranges;   // {first, count} per chain
   uint32_t n_nodes;
   uint32_t has_media;
   uint32_t root_code;  // traversal entry code of the root record
@@ -242,7 +244,12 @@ RT_DEV bool sphere_t(V3 c, double radius, V3 o, V3 d, double a, double tmin, dou
 }
 
 // AxisAlignedRect::hit up to the containment test (rect.rs:39-51).
-RT_DEV bool rect_t(const DPrim& pr, V3 o, V3 d, double tmin, double tmax, double& t) {
+// `overhang`: for a record tied to the reference's box chain (kChainBit), is the hit point
+// outside, or within rounding of the edge of, its cuboid's bounding box?  The Y side of a
+// cuboid spans the box's z half-extent along x and its x half-extent along z (cuboid.rs:21-30),
+// so the box's extent along one in-plane axis is the side's extent along the other.  A point
+// well inside the box is inside every box of the chain, which then cannot reject the ray.
+RT_DEV bool rect_t(const DPrim& pr, V3 o, V3 d, double tmin, double tmax, double& t, bool& overhang) {
   uint32_t d0 = (pr.kind >> 4) & 3u;
   uint32_t d1 = d0 == 2 ? 0 : d0 + 1;
   uint32_t d2 = d1 == 2 ? 0 : d1 + 1;
@@ -252,6 +259,12 @@ RT_DEV bool rect_t(const DPrim& pr, V3 o, V3 d, double tmin, double tmax, double
   double j = vget(o, d2) + tt * vget(d, d2);
   if (!(pr.p[1] <= i && i <= pr.p[2]) || !(pr.p[3] <= j && j <= pr.p[4])) return false;
   t = tt;
+  if (pr.kind & kChainBit) {
+    const double keep = 0.999999;
+    double half_i = 0.5 * (pr.p[4] - pr.p[3]) * keep, half_j = 0.5 * (pr.p[2] - pr.p[1]) * keep;
+    double ci = 0.5 * (pr.p[1] + pr.p[2]), cj = 0.5 * (pr.p[3] + pr.p[4]);
+    overhang = !(fabs(i - ci) < half_i && fabs(j - cj) < half_j);
+  }
   return true;
 }
 
@@ -260,7 +273,7 @@ RT_DEV bool rect_t(const DPrim& pr, V3 o, V3 d, double tmin, double tmax, double
 // `dd` = d.d of the ray as given (used as is when the primitive has no wrappers).
 template <bool STATS>
 RT_DEV bool base_prim_t(const DeviceScene& sc, const DPrim& pr, V3 o, V3 d, double dd, double time,
-                        double tmin, double tmax, double& t, Stats& st) {
+                        double tmin, double tmax, double& t, Stats& st, bool& overhang) {
   uint32_t n_ops = ops_count(pr.ops);
   if (n_ops) {
     ops_forward<STATS>(sc, pr.ops, n_ops, o, d, st);
@@ -276,7 +289,7 @@ RT_DEV bool base_prim_t(const DeviceScene& sc, const DPrim& pr, V3 o, V3 d, doub
     return sphere_t<STATS>(moving_center(sc, pr, time), pr.p[3], o, d, dd, tmin, tmax, t, st);
   }
   stat<STATS>(st, RT_STAT_RECT_TESTS);
-  return rect_t(pr, o, d, tmin, tmax, t);
+  return rect_t(pr, o, d, tmin, tmax, t, overhang);
 }
 
 // boundary.hit(ray, range).t for a medium: first minimum over its primitives
@@ -288,7 +301,8 @@ RT_DEV bool boundary_t(const DeviceScene& sc, uint32_t first, uint32_t count, V3
   for (uint32_t k = 0; k < count; ++k) {
     const DPrim pr = sc.boundary[first + k];
     double tk;
-    if (base_prim_t<STATS>(sc, pr, o, d, vlen2(d), time, tmin, tmax, tk, st)) {
+    bool unused = false;
+    if (base_prim_t<STATS>(sc, pr, o, d, vlen2(d), time, tmin, tmax, tk, st, unused)) {
       if (!any || tk < t) t = tk;
       any = true;
     }
@@ -544,6 +558,34 @@ RT_DEV DPrim load_prim(const DeviceScene& sc, const LdsScene& lds, uint32_t slot
   return u.p;
 }
 
+// Would the reference's own hierarchy let this ray reach the leaf list of chain `chain`?
+// BvhNode::hit (bvh.rs:82-87) at every node from the root down, each with
+// Aabb::intersect (aabb.rs:35-50) over the full range tmin..inf.  Asked only for hits
+// on geometry outside its object's bounding_box() (records with kChainBit).
+RT_DEV bool reference_chain_passes(const DeviceScene& sc, uint32_t chain, V3 o, V3 d, double tmin) {
+  const double inf = __longlong_as_double(0x7FF0000000000000ll);
+  const uint32_t first = sc.chain_ranges[2u * chain], count = sc.chain_ranges[2u * chain + 1u];
+  const double inv[3] = {1.0 / d.x, 1.0 / d.y, 1.0 / d.z};  // f64::recip
+  const double org[3] = {o.x, o.y, o.z};
+  for (uint32_t k = 0; k < count; ++k) {
+    const double* b = sc.chain_boxes + 6u * (size_t)(first + k);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      double t0 = (b[a] + -org[a]) * inv[a];
+      double t1 = (b[3 + a] + -org[a]) * inv[a];
+      if (inv[a] < 0.0) {
+        double t = t0;
+        t0 = t1;
+        t1 = t;
+      }
+      // f64::max / f64::min: a NaN operand is ignored
+      double t_min = fmax(t0, tmin), t_max = fmin(t1, inf);
+      if (t_max <= t_min) return false;
+    }
+  }
+  return true;
+}
+
 // world.hit(ray, tmin..inf): closest t over the flattened BVH.
 //
 // A traversal entry is a code for what a record's (a, b) say:
@@ -584,7 +626,9 @@ RT_HD uint32_t stack_t_bits(float t, uint32_t bits) {
   return (u >> (bits - 1u)) << (bits - 1u);
 }
 
-template <bool STATS, bool MEDIA>
+// MEDIA: constant media are tested (else skipped); CHAINS: records tied to the reference's
+// box chain are checked against it.
+template <bool STATS, bool MEDIA, bool CHAINS = MEDIA>
 RT_DEV Closest closest_hit(const DeviceScene& sc, const LdsScene& lds, V3 o, V3 d, double time,
                            double tmin, const DrawKey& key, Stats& st) {
   lds_u32* stack = lds.stack;
@@ -683,12 +727,16 @@ RT_DEV Closest closest_hit(const DeviceScene& sc, const LdsScene& lds, V3 o, V3 
       const DPrim pr = load_prim(sc, lds, slot);
       double t;
       bool hit;
+      bool overhang = true;  // (a flagged medium always answers to the chain)
       if (MEDIA && (pr.kind & 15u) == DP_MEDIUM)
         hit = medium_t<STATS>(sc, pr, o, d, time, tmin, inf, key, t, st);
       else if (!MEDIA && (pr.kind & 15u) == DP_MEDIUM)
         hit = false;
       else
-        hit = base_prim_t<STATS>(sc, pr, o, d, dd, time, tmin, inf, t, st);
+        hit = base_prim_t<STATS>(sc, pr, o, d, dd, time, tmin, inf, t, st, overhang);
+      if (CHAINS && hit && (pr.kind & kChainBit) && overhang)  // a hit outside its object's box
+        hit = reference_chain_passes(sc, (uint32_t)pr.p[(pr.kind & 15u) == DP_MEDIUM ? 3 : 5], o, d,
+                                     tmin);
       if (hit) {
         if (t < best.t || (t == best.t && best.item != kNoPrim &&
                            sc.ranks[slot] < sc.ranks[best.item])) {

@@ -95,6 +95,46 @@ def test_sample_ranges_add_up(gpu_ctx, golden_dir):
     assert np.abs(whole - (lo + hi)).max() <= 1e-13 * np.abs(whole).max()
 
 
+@pytest.mark.parametrize("pipeline", ["default", "binned"])
+def test_pass_size_does_not_change_the_image(gpu_ctx, golden_dir, pipeline):
+    """A small path budget splits the samples into several passes; the per-pixel sums stay in sample order."""
+    from raytracer_amd import abi
+    from raytracer_amd.render import Context
+    scene, g = load(golden_dir, "book_cover")
+    w, h = scene.width, scene.height
+    flags = abi.RT_FLAG_BINNED if pipeline == "binned" else 0
+    gpu_ctx.upload(scene)
+    one = gpu_ctx.render(gpu_ctx.params(w, h, 0, 7, 50, seed=11, flags=flags), dtype=np.float64)
+    small = Context(device=0, max_paths_in_flight=2 * w * h + 5)  # 2 samples per pass: 4 passes
+    try:
+        small.upload(scene)
+        many = small.render(small.params(w, h, 0, 7, 50, seed=11, flags=flags), dtype=np.float64)
+    finally:
+        small.close()
+    assert np.array_equal(one, many)
+
+
+@pytest.mark.parametrize("pipeline", ["default", "binned"])
+def test_overhanging_cuboid_sides_follow_the_reference_boxes(gpu_ctx, pipeline):
+    """First hits and radiance against the reference-topology oracle on a scene whose cuboid Y
+    sides reach outside their bounding boxes (plain, rotated+translated, and as a medium)."""
+    from raytracer_amd import abi
+    from raytracer_amd.scene import HostScene
+    from test_abi import OVERHANG_SCENE
+    scene = HostScene.load_ron_text(OVERHANG_SCENE)
+    gpu_ctx.upload(scene)
+    w, h = 64, 48
+    o = po.Oracle(scene.view_ptr)
+    ids, t, n = gpu_ctx.first_hit(w, h)
+    rid, rt_, rn = o.first_hit(w, h)
+    assert np.array_equal(ids, rid)
+    assert np.array_equal(t, rt_) and np.array_equal(n, rn)
+    flags = abi.RT_FLAG_BINNED if pipeline == "binned" else 0
+    img = gpu_ctx.render(gpu_ctx.params(w, h, 0, 3, 6, seed=4, flags=flags), dtype=np.float64)
+    ref = o.render(po.make_params(w, h, 0, 3, 6, 4), po.MODE_ITERATIVE, threads=2)
+    assert np.allclose(img, ref, rtol=1e-9, atol=1e-12)  # log10 in the medium: last-place libm differences
+
+
 def test_stats_match_flat_oracle(gpu_ctx, golden_dir):
     """The device walks the flattened BVH exactly as the instrumented CPU traversal does."""
     from raytracer_amd.render import build_bvh

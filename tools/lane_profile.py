@@ -28,7 +28,8 @@ ctx.upload(scene)
 lib = abi.device_lib()
 out = (ctypes.c_ulonglong * 32)()
 lib.rt_debug_lane_trips(out, 32)
-img, st = ctx.render(ctx.params(w, h, 0, spp, scene.max_depth, seed=1, flags=flags), dtype=np.float32, stats=True)
+depth = int(os.environ.get("LP_DEPTH", scene.max_depth))
+img, st = ctx.render(ctx.params(w, h, 0, spp, depth, seed=1, flags=flags), dtype=np.float32, stats=True)
 n = lib.rt_debug_lane_trips(out, 32)
 rays = int(st[0])
 print(f"{name} {w}x{h} spp {spp}: rays {rays}")
