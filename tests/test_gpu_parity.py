@@ -156,6 +156,31 @@ def test_stats_match_flat_oracle(gpu_ctx, golden_dir):
     assert list(st[:16]) == list(rs[:16])
 
 
+def test_degenerate_requests(gpu_ctx, golden_dir):
+    """No objects, no samples, no depth: what main.rs:82-101 would produce for them."""
+    from raytracer_amd.scene import HostScene
+    import test_oracle_kat as kat
+    empty = HostScene.load_ron_text(kat.SCENE_HEAD + "\n  ]\n)")
+    gpu_ctx.upload(empty)
+    w, h = 64, 64
+    img = gpu_ctx.render(gpu_ctx.params(w, h, 0, 3, 5, seed=1), dtype=np.float64)
+    assert np.array_equal(img, np.broadcast_to(3 * np.array([0.5, 0.7, 1.0]), (h, w, 3)))  # background x 3
+    ids, t, n = gpu_ctx.first_hit(w, h)
+    assert (ids == 0xFFFFFFFF).all() and not t.any() and not n.any()
+    scene, g = load(golden_dir, "material_demo")
+    gpu_ctx.upload(scene)
+    w, h = scene.width, scene.height
+    assert not gpu_ctx.render(gpu_ctx.params(w, h, 5, 5, 50, seed=1), dtype=np.float64).any()  # no samples
+    assert not gpu_ctx.render(gpu_ctx.params(w, h, 0, 2, 0, seed=1), dtype=np.float64).any()   # ray_color(depth 0)
+    one = gpu_ctx.render(gpu_ctx.params(w, h, 0, 2, 1, seed=1), dtype=np.float64)  # depth 1: emitted or sky only
+    o = po.Oracle(scene.view_ptr)
+    assert np.array_equal(one, o.render(po.make_params(w, h, 0, 2, 1, 1), po.MODE_ITERATIVE, threads=2))
+    edge = (w - 3, h - 2, 3, 2)  # a window in the last rows and columns
+    part = gpu_ctx.render(gpu_ctx.params(w, h, 0, 2, 50, seed=1, window=edge), dtype=np.float64)
+    full = gpu_ctx.render(gpu_ctx.params(w, h, 0, 2, 50, seed=1), dtype=np.float64)
+    assert np.array_equal(part, full[h - 2:, w - 3:])
+
+
 def test_errors_are_reported(gpu_ctx, golden_dir):
     from raytracer_amd.abi import RtError
     scene, g = load(golden_dir, "material_demo")
