@@ -584,7 +584,7 @@ std::string flatten_scene(const rt_scene& s, FlatScene& out, int& code) {
       d.p[2] = p.center[2];
       d.p[3] = p.radius;
       d.p[4] = p.time0;
-      d.p[5] = (double)out.aux.size();
+      d.p5 = (double)out.aux.size();
       out.aux.push_back(DAux{{p.center1[0], p.center1[1], p.center1[2], p.time1}});
     } else {
       d.kind = DP_RECT | (p.axis << 4);
@@ -598,7 +598,7 @@ std::string flatten_scene(const rt_scene& s, FlatScene& out, int& code) {
       const rt_object& o = s.objects[object];
       if (!o.is_medium && p.axis == 1 && cuboid_overhangs(o)) {
         d.kind |= kChainBit;
-        d.p[5] = (double)chains.chain_of_object[object];
+        d.p5 = (double)chains.chain_of_object[object];
       }
     }
     d.kind |= (m.kind & 7u) << 8;

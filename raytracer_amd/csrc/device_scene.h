@@ -18,24 +18,28 @@ enum DPrimKind : uint32_t {
   DP_MEDIUM = 3
 };
 
-// 64-byte primitive record.
+// 64-byte primitive record: 48 bytes the traversal reads for every test (staged in
+// LDS), then 16 bytes only shading and the rarer kinds need (read from global memory).
 //   kind word: bits 0-3 DPrimKind, bits 4-5 rect axis, bits 8-10 material kind
 //              (rt_material_kind) of `material`, bit 11 "texture needs (u,v)",
 //              bit 12 "a hit counts only if the ray passes the reference's box chain"
 //              (a cuboid side that sticks out of Cuboid::bounding_box, see FlatScene::chain_boxes).
 //   ops word : first op (low 24 bits) | op count (high 8 bits), outermost first.
-//   sphere        p = {cx, cy, cz, radius, -, -}
-//   moving sphere p = {c0x, c0y, c0z, radius, time0, aux index}; aux = {c1x, c1y, c1z, time1}
-//   rect          p = {center[axis], min[d1], max[d1], min[d2], max[d2], chain (bit 12)}
+//   sphere        p = {cx, cy, cz, radius, -}
+//   moving sphere p = {c0x, c0y, c0z, radius, time0}, p5 = aux index; aux = {c1x, c1y, c1z, time1}
+//   rect          p = {center[axis], min[d1], max[d1], min[d2], max[d2]}, p5 = chain (bit 12)
 //                 (d1 = axis.next(), d2 = d1.next(); min/max as rect.rs:20-34 computes them)
-//   medium        p = {neg_inv_density, first boundary prim, boundary prim count, chain (bit 12), -, -}
+//   medium        p = {neg_inv_density, first boundary prim, boundary prim count, chain (bit 12), -}
 struct DPrim {
-  double p[6];
+  double p[5];
   uint32_t kind;
   uint32_t ops;
+  // --- the first 48 bytes end here ---
+  double p5;
   uint32_t material;
   uint32_t object;
 };
+const uint32_t kPrimHotBytes = 48;
 static_assert(sizeof(DPrim) == 64, "DPrim must be 64 bytes");
 
 struct DOp {  // 32 bytes

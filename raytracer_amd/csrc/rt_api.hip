@@ -476,7 +476,7 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
       } else {
         stat<STATS>(st, RT_STAT_HITS);
         RT_LP(st, LP_SHADE);
-        const DPrim pr = load_prim(sc, lds, h.item);
+        const DPrim pr = load_prim<true>(sc, lds, h.item);
         so = shade_begin<STATS, true>(sc, (h.kind >> 8) & 7u, pr, o, d, time, h.t, key, st);
         if (so.emits) {
           add = vmul(beta, so.emitted);
@@ -771,8 +771,8 @@ LdsLayout plan_lds(const FlatScene& f, uint32_t block, uint32_t budget) {
   // (+3: the never-hit records that end the device copy, so the last group stays in LDS)
   l.n_nodes = std::min<uint32_t>((uint32_t)f.nodes.size() + 3u, room / 32u);
   room -= l.n_nodes * 32u;
-  l.n_prims = std::min<uint32_t>((uint32_t)f.prims.size(), room / 64u);
-  l.bytes = used + l.n_nodes * 32u + l.n_prims * 64u;
+  l.n_prims = std::min<uint32_t>((uint32_t)f.prims.size(), room / kPrimHotBytes);
+  l.bytes = used + l.n_nodes * 32u + l.n_prims * kPrimHotBytes;
   return l;
 }
 
@@ -1066,7 +1066,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* scene) {
     if (const char* e = getenv("MI355RT_LDS_PRIMS")) {
       LdsLayout& l = ctx->lds;
       uint32_t n = std::min<uint32_t>(l.n_prims, (uint32_t)strtoul(e, nullptr, 10));
-      l.bytes -= (l.n_prims - n) * 64u;
+      l.bytes -= (l.n_prims - n) * kPrimHotBytes;
       l.n_prims = n;
     }
     uint32_t tb = 512u;

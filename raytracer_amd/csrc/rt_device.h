@@ -211,7 +211,7 @@ RT_DEV void ops_backward(const DeviceScene& sc, uint32_t ops_word, V3 world_dir,
 }
 
 RT_DEV V3 moving_center(const DeviceScene& sc, const DPrim& pr, double time) {  // moving_sphere.rs:20-23
-  const DAux ax = sc.aux[(uint32_t)pr.p[5]];
+  const DAux ax = sc.aux[(uint32_t)pr.p5];
   double t0 = pr.p[4], t1 = ax.v[3];
   double portion = (t0 - time) / (t1 - t0);
   V3 c0 = v3(pr.p[0], pr.p[1], pr.p[2]), c1 = v3(ax.v[0], ax.v[1], ax.v[2]);
@@ -453,7 +453,7 @@ typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 struct LdsScene {
   const lds_f32x4* nodes;
-  const lds_f32x4* prims;  // 4 x 16 bytes per DPrim
+  const lds_f32x4* prims;  // the first 3 x 16 bytes of each DPrim
   lds_u32* stack;          // this lane's column of packed entries, `stack_stride` words apart
   uint32_t n_nodes, n_prims, stack_stride, entry_bits;
 };
@@ -464,11 +464,11 @@ RT_DEV LdsScene lds_stage(const DeviceScene& sc, const LdsLayout& lay, char* sme
                           uint32_t block) {
   lds_f32x4* nodes = (lds_f32x4*)smem;
   lds_f32x4* prims = nodes + 2u * lay.n_nodes;
-  lds_u32* stack = (lds_u32*)(prims + 4u * lay.n_prims);
+  lds_u32* stack = (lds_u32*)(prims + 3u * lay.n_prims);
   const f32x4* gn = (const f32x4*)sc.nodes;
   const f32x4* gp = (const f32x4*)sc.prims;
   for (uint32_t i = tid; i < 2u * lay.n_nodes; i += block) nodes[i] = gn[i];
-  for (uint32_t i = tid; i < 4u * lay.n_prims; i += block) prims[i] = gp[i];
+  for (uint32_t i = tid; i < 3u * lay.n_prims; i += block) prims[i] = gp[4u * (i / 3u) + i % 3u];
   __syncthreads();
   LdsScene l;
   l.nodes = nodes;
@@ -542,19 +542,27 @@ RT_DEV V3 wave_rand_in_unit_sphere(bool need, const DrawKey& key, lds_u32* xch, 
   return v;
 }
 
+// Leaf slot `slot` as the traversal needs it: the first 48 bytes from LDS when staged, and
+// the rest only for the kinds that read it (a moving sphere's second centre, a medium's
+// object id, a chain id).
+// FULL: always the whole record (shading reads material and object).
+template <bool FULL>
 RT_DEV DPrim load_prim(const DeviceScene& sc, const LdsScene& lds, uint32_t slot) {
   union {
     f32x4 q[4];
     DPrim p;
   } u;
+  const f32x4* g = (const f32x4*)(sc.prims + slot);
   if (slot < lds.n_prims) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) u.q[k] = lds.prims[4u * slot + k];
+    for (int k = 0; k < 3; ++k) u.q[k] = lds.prims[3u * slot + k];
   } else {
-    const f32x4* g = (const f32x4*)(sc.prims + slot);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) u.q[k] = g[k];
+    for (int k = 0; k < 3; ++k) u.q[k] = g[k];
   }
+  u.q[3] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const uint32_t kind = u.p.kind & 15u;  // (a medium draws with its object id)
+  if (FULL || kind == DP_MOVING_SPHERE || kind == DP_MEDIUM || (u.p.kind & kChainBit)) u.q[3] = g[3];
   return u.p;
 }
 
@@ -724,7 +732,7 @@ RT_DEV Closest closest_hit(const DeviceScene& sc, const LdsScene& lds, V3 o, V3 
     for (uint32_t k = 0; k < leaf_count; ++k) {
       RT_LP(st, LP_LEAFPRIM);
       uint32_t slot = leaf_first + k;
-      const DPrim pr = load_prim(sc, lds, slot);
+      const DPrim pr = load_prim<false>(sc, lds, slot);
       double t;
       bool hit;
       bool overhang = true;  // (a flagged medium always answers to the chain)
@@ -735,7 +743,7 @@ RT_DEV Closest closest_hit(const DeviceScene& sc, const LdsScene& lds, V3 o, V3 
       else
         hit = base_prim_t<STATS>(sc, pr, o, d, dd, time, tmin, inf, t, st, overhang);
       if (CHAINS && hit && (pr.kind & kChainBit) && overhang)  // a hit outside its object's box
-        hit = reference_chain_passes(sc, (uint32_t)pr.p[(pr.kind & 15u) == DP_MEDIUM ? 3 : 5], o, d,
+        hit = reference_chain_passes(sc, (uint32_t)((pr.kind & 15u) == DP_MEDIUM ? pr.p[3] : pr.p5), o, d,
                                      tmin);
       if (hit) {
         if (t < best.t || (t == best.t && best.item != kNoPrim &&
