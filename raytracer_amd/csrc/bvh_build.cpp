@@ -686,10 +686,6 @@ std::string flatten_scene(const rt_scene& s, FlatScene& out, int& code) {
     code = RT_ERR_LIMIT;
     return "acceleration structure too large for the packed traversal entries";
   }
-  if (out.stack_entries > kMaxStackEntries) {
-    code = RT_ERR_LIMIT;
-    return "acceleration structure needs a deeper traversal stack than LDS holds";
-  }
   code = RT_OK;
   return "";
 }

@@ -78,7 +78,6 @@ struct DImage {  // 16 bytes
 };
 
 const uint32_t kMaxBvhDepth = 32;      // levels of the binary tree the wide one is collapsed from
-const uint32_t kMaxStackEntries = 64;  // 8-byte traversal stack entries per lane that LDS can hold
 const uint32_t kMaxLeafItems = 8;     // upper bound; the builder's default is lower
 const uint32_t kNoPrim = 0xFFFFFFFFu;
 const uint32_t kChainBit = 1u << 12;

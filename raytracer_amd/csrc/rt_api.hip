@@ -23,6 +23,7 @@
 #include <new>
 #include <string>
 #include <limits>
+#include <type_traits>
 #include <vector>
 
 #include "rt_device.h"
@@ -149,8 +150,11 @@ raygen_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps) {
 }
 
 // --------------------------------------------------------------- extend
-template <bool STATS, bool MEDIA>
-__global__ void __launch_bounds__(kBlock)
+#ifndef RT_EXTEND_MEDIA_WAVES
+#define RT_EXTEND_MEDIA_WAVES 3
+#endif
+template <bool STATS, bool MEDIA, bool OVERFLOW>
+__global__ void __launch_bounds__(kBlock, MEDIA ? RT_EXTEND_MEDIA_WAVES : 4)  // waves per SIMD to fit registers for
 extend_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_t bounce,
               unsigned long long* g_stats) {
   extern __shared__ __align__(16) char smem[];
@@ -180,7 +184,7 @@ extend_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32
       uint32_t x = ps.x0 + local % ps.ww, y = ps.y0 + local / ps.ww;
       DrawKey key{ps.seed, y * ps.width + x, ps.sample_base + s_local, bounce};
       stat<STATS>(st, RT_STAT_RAYS);
-      Closest h = closest_hit<STATS, MEDIA>(sc, lds, v3(ro.x, ro.y, ro.z), v3(rdv.x, rdv.y, rdv.z),
+      Closest h = closest_hit<STATS, MEDIA, MEDIA, OVERFLOW>(sc, lds, v3(ro.x, ro.y, ro.z), v3(rdv.x, rdv.y, rdv.z),
                                             ro.w, 0.001, key, st);
       pb.hit_item[path] = h.item;
       if (h.item != kNoPrim) {
@@ -411,7 +415,7 @@ RT_DEV void wave_flush(const uint32_t* stage, uint32_t n, uint32_t* g_counter, u
   wave_lds_sync();
 }
 
-template <int BLOCK, bool STATS, bool MEDIA>
+template <int BLOCK, bool STATS, bool MEDIA, bool OVERFLOW>
 __global__ void __launch_bounds__(BLOCK, 4)  // registers for four waves per SIMD
 trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_t bounce,
              uint32_t max_depth, unsigned long long* g_stats) {
@@ -459,7 +463,7 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
       }
       stat<STATS>(st, RT_STAT_RAYS);
       RT_LP(st, LP_RAY);
-      Closest h = closest_hit<STATS, MEDIA>(sc, lds, o, d, time, 0.001, key, st);
+      Closest h = closest_hit<STATS, MEDIA, MEDIA, OVERFLOW>(sc, lds, o, d, time, 0.001, key, st);
       // ... and starts from beta = 1, L = 0
       V3 beta = v3(1.0, 1.0, 1.0);
       if (bounce != 0) {
@@ -569,14 +573,24 @@ to_float_kernel(const double* in, float* out, uint64_t n) {
 }
 
 // ------------------------------------------------------------ first hit
-template <bool CHAINS>
+template <bool CHAINS, bool OVERFLOW>
+RT_DEV void first_hit_pixel(const DeviceScene& sc, const LdsScene& lds, const PassInfo& ps,
+                            uint32_t local, uint32_t* id, double* t_out, double* normal);
+
+template <bool CHAINS, bool OVERFLOW>
 __global__ void __launch_bounds__(kBlock)
 first_hit_kernel(DeviceScene sc, LdsLayout lay, PassInfo ps, uint32_t* id, double* t_out,
                  double* normal) {
   extern __shared__ __align__(16) char smem[];
   const LdsScene lds = lds_stage(sc, lay, smem, threadIdx.x, kBlock);
-  uint32_t local = blockIdx.x * kBlock + threadIdx.x;
-  if (local >= ps.n_pixels) return;
+  for (uint32_t local = blockIdx.x * kBlock + threadIdx.x; local < ps.n_pixels;
+       local += gridDim.x * kBlock)
+    first_hit_pixel<CHAINS, OVERFLOW>(sc, lds, ps, local, id, t_out, normal);
+}
+
+template <bool CHAINS, bool OVERFLOW>
+RT_DEV void first_hit_pixel(const DeviceScene& sc, const LdsScene& lds, const PassInfo& ps,
+                            uint32_t local, uint32_t* id, double* t_out, double* normal) {
   uint32_t x = ps.x0 + local % ps.ww, y = ps.y0 + local / ps.ww;
   double u = ((double)x + 0.5) / ((double)ps.width - 1.0);
   double v = ((double)(ps.height - y) + 0.5) / ((double)ps.height - 1.0);
@@ -589,7 +603,7 @@ first_hit_kernel(DeviceScene sc, LdsLayout lay, PassInfo ps, uint32_t* id, doubl
                 offset);
   DrawKey key{0, 0, 0, 0};
   Stats st;
-  Closest h = closest_hit<false, false, CHAINS>(sc, lds, origin, dir, c.time0, 0.001, key, st);
+  Closest h = closest_hit<false, false, CHAINS, OVERFLOW>(sc, lds, origin, dir, c.time0, 0.001, key, st);
   if (h.item == kNoPrim) {
     id[local] = 0xFFFFFFFFu;
     t_out[local] = 0.0;
@@ -658,6 +672,8 @@ struct rt_ctx {
   LdsLayout lds_trace{};        // layout for trace_kernel's workgroup size
   uint32_t trace_block = 256;   // threads per trace_kernel workgroup: 256, 512 or 1024
   uint32_t trace_blocks_per_cu = 16;
+  uint32_t blocks_per_cu = 16;  // 256-thread workgroups per CU in a grid (extend, shade, first hit)
+  DeviceArray<uint32_t> stack_overflow;
   std::vector<hipEvent_t> events;  // RT_FLAG_TIMING: three per bounce (before extend, between, after shade)
 };
 
@@ -759,11 +775,13 @@ uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); 
 // LDS plan for workgroups of `block` threads within `budget` bytes: the traversal
 // stack first (it is not optional), then as many top-of-tree records as fit, then
 // leaf slots with what is left.
-LdsLayout plan_lds(const FlatScene& f, uint32_t block, uint32_t budget) {
+LdsLayout plan_lds(const FlatScene& f, uint32_t block, uint32_t budget, uint32_t stack_cap) {
   LdsLayout l{};
-  // one spare: a visit stores before it knows whether it keeps; two rows at least: they double as
-  // the exchange area of wave_rand_in_unit_sphere
-  l.stack_depth = std::max(f.stack_entries + 1u, 2u);
+  // one spare entry: a visit stores before it knows whether it keeps; two rows at least: they
+  // double as the exchange area of wave_rand_in_unit_sphere.  The worst-case need can be several
+  // times what a ray ever uses; entries beyond stack_cap go to the global overflow area.
+  const uint32_t need = std::max(f.stack_entries + 1u, 2u);
+  l.stack_depth = std::min(need, std::max(stack_cap, 2u));
   l.entry_bits = entry_code_bits((uint32_t)f.nodes.size(), (uint32_t)f.items.size());
   uint32_t used = l.stack_depth * block * (uint32_t)sizeof(uint32_t);
   budget = std::max(budget, used + 4096u);  // leave room for a few records
@@ -776,17 +794,25 @@ LdsLayout plan_lds(const FlatScene& f, uint32_t block, uint32_t budget) {
   return l;
 }
 
+// A run-time bool as a compile-time one: f(std::true_type) or f(std::false_type).
+template <typename F>
+auto with_bool(bool v, F&& f) {
+  return v ? f(std::true_type{}) : f(std::false_type{});
+}
+
 template <int BLOCK>
 void launch_trace_block(rt_ctx* ctx, bool stats, bool media, uint32_t grid, const PathBuffers& pb,
                         const PassInfo& ps, uint32_t b, uint32_t max_depth, unsigned long long* gs) {
   const LdsLayout& l = ctx->lds_trace;
-  if (stats) {
-    if (media) trace_kernel<BLOCK, true, true><<<grid, BLOCK, l.bytes, ctx->stream>>>(ctx->ds, l, pb, ps, b, max_depth, gs);
-    else trace_kernel<BLOCK, true, false><<<grid, BLOCK, l.bytes, ctx->stream>>>(ctx->ds, l, pb, ps, b, max_depth, gs);
-  } else {
-    if (media) trace_kernel<BLOCK, false, true><<<grid, BLOCK, l.bytes, ctx->stream>>>(ctx->ds, l, pb, ps, b, max_depth, gs);
-    else trace_kernel<BLOCK, false, false><<<grid, BLOCK, l.bytes, ctx->stream>>>(ctx->ds, l, pb, ps, b, max_depth, gs);
-  }
+  with_bool(stats, [&](auto S) {
+    return with_bool(media, [&](auto M) {
+      return with_bool(l.overflow != nullptr, [&](auto O) {
+        trace_kernel<BLOCK, decltype(S)::value, decltype(M)::value, decltype(O)::value>
+            <<<grid, BLOCK, l.bytes, ctx->stream>>>(ctx->ds, l, pb, ps, b, max_depth, gs);
+        return 0;
+      });
+    });
+  });
 }
 void launch_trace(rt_ctx* ctx, bool stats, bool media, uint32_t grid, const PathBuffers& pb,
                   const PassInfo& ps, uint32_t b, uint32_t max_depth, unsigned long long* gs) {
@@ -794,13 +820,56 @@ void launch_trace(rt_ctx* ctx, bool stats, bool media, uint32_t grid, const Path
   else if (ctx->trace_block == 512) launch_trace_block<512>(ctx, stats, media, grid, pb, ps, b, max_depth, gs);
   else launch_trace_block<256>(ctx, stats, media, grid, pb, ps, b, max_depth, gs);
 }
+void launch_extend(rt_ctx* ctx, bool stats, bool media, uint32_t grid, const PathBuffers& pb,
+                   const PassInfo& ps, uint32_t b, unsigned long long* gs) {
+  const LdsLayout& l = ctx->lds;
+  with_bool(stats, [&](auto S) {
+    return with_bool(media, [&](auto M) {
+      return with_bool(l.overflow != nullptr, [&](auto O) {
+        extend_kernel<decltype(S)::value, decltype(M)::value, decltype(O)::value>
+            <<<grid, kBlock, l.bytes, ctx->stream>>>(ctx->ds, l, pb, ps, b, gs);
+        return 0;
+      });
+    });
+  });
+}
+// Kernels that may be launched with more than the default dynamic LDS limit.
 template <int BLOCK>
 hipError_t allow_trace_lds(int bytes) {
   const hipFuncAttribute attr = hipFuncAttributeMaxDynamicSharedMemorySize;
-  hipError_t e = hipFuncSetAttribute((const void*)trace_kernel<BLOCK, false, false>, attr, bytes);
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)trace_kernel<BLOCK, false, true>, attr, bytes);
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)trace_kernel<BLOCK, true, false>, attr, bytes);
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)trace_kernel<BLOCK, true, true>, attr, bytes);
+  hipError_t e = hipSuccess;
+  for (int v = 0; v < 8 && e == hipSuccess; ++v)
+    e = with_bool(v & 1, [&](auto S) {
+      return with_bool(v & 2, [&](auto M) {
+        return with_bool(v & 4, [&](auto O) {
+          return hipFuncSetAttribute(
+              (const void*)trace_kernel<BLOCK, decltype(S)::value, decltype(M)::value, decltype(O)::value>,
+              attr, bytes);
+        });
+      });
+    });
+  return e;
+}
+hipError_t allow_extend_lds(int bytes) {
+  const hipFuncAttribute attr = hipFuncAttributeMaxDynamicSharedMemorySize;
+  hipError_t e = hipSuccess;
+  for (int v = 0; v < 8 && e == hipSuccess; ++v)
+    e = with_bool(v & 1, [&](auto S) {
+      return with_bool(v & 2, [&](auto M) {
+        return with_bool(v & 4, [&](auto O) {
+          return hipFuncSetAttribute(
+              (const void*)extend_kernel<decltype(S)::value, decltype(M)::value, decltype(O)::value>, attr,
+              bytes);
+        });
+      });
+    });
+  for (int v = 0; v < 4 && e == hipSuccess; ++v)
+    e = with_bool(v & 1, [&](auto C) {
+      return with_bool(v & 2, [&](auto O) {
+        return hipFuncSetAttribute((const void*)first_hit_kernel<decltype(C)::value, decltype(O)::value>,
+                                   attr, bytes);
+      });
+    });
   return e;
 }
 
@@ -867,9 +936,7 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats) {
   uint32_t per_pass = (uint32_t)std::min<uint64_t>(ctx->max_paths / n_pix, n_samples);
   if (per_pass == 0) per_pass = 1;
   const PathBuffers& pb = ctx->pb;
-  uint32_t blocks_per_cu = 16u;
-  if (const char* e = getenv("MI355RT_BLOCKS_PER_CU")) blocks_per_cu = (uint32_t)strtoul(e, nullptr, 10);
-  const uint32_t max_grid = ctx->n_cus * std::max(1u, blocks_per_cu);
+  const uint32_t max_grid = ctx->n_cus * ctx->blocks_per_cu;
   // the MEDIA kernels carry the rare cases: constant media and records tied to the reference's box chain
   const bool media = ctx->flat.has_media || !ctx->flat.chain_ranges.empty();
   bool solid = true;
@@ -879,7 +946,6 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats) {
   const bool fused = solid && !(p->flags & RT_FLAG_BINNED);
   uint32_t bins_present = 1u;
   for (const DMaterial& m : ctx->flat.materials) bins_present |= 2u << m.kind;
-  const LdsLayout lds = ctx->lds;
   rc = ensure_paths(ctx, n_pix * per_pass, p->max_depth, !fused);
   if (rc != RT_OK) return rc;
 
@@ -906,18 +972,16 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats) {
         // cheap shading: traversal and scatter in one kernel per bounce
         launch_trace(ctx, want_stats, media, tgrid, pb, ps, b, p->max_depth, gs);
         if (want_timing) RT_HIP(ctx, stamp());
-      } else if (want_stats) {
-        if (media) extend_kernel<true, true><<<grid, kBlock, lds.bytes, ctx->stream>>>(ctx->ds, lds, pb, ps, b, gs);
-        else extend_kernel<true, false><<<grid, kBlock, lds.bytes, ctx->stream>>>(ctx->ds, lds, pb, ps, b, gs);
-        if (want_timing) RT_HIP(ctx, stamp());
-        if (solid) launch_shade<true, true>(bins_present, grid, ctx->stream, ctx->ds, pb, ps, b, p->max_depth, gs);
-        else launch_shade<true, false>(bins_present, grid, ctx->stream, ctx->ds, pb, ps, b, p->max_depth, gs);
       } else {
-        if (media) extend_kernel<false, true><<<grid, kBlock, lds.bytes, ctx->stream>>>(ctx->ds, lds, pb, ps, b, gs);
-        else extend_kernel<false, false><<<grid, kBlock, lds.bytes, ctx->stream>>>(ctx->ds, lds, pb, ps, b, gs);
+        launch_extend(ctx, want_stats, media, grid, pb, ps, b, gs);
         if (want_timing) RT_HIP(ctx, stamp());
-        if (solid) launch_shade<false, true>(bins_present, grid, ctx->stream, ctx->ds, pb, ps, b, p->max_depth, gs);
-        else launch_shade<false, false>(bins_present, grid, ctx->stream, ctx->ds, pb, ps, b, p->max_depth, gs);
+        with_bool(want_stats, [&](auto S) {
+          return with_bool(solid, [&](auto T) {
+            launch_shade<decltype(S)::value, decltype(T)::value>(bins_present, grid, ctx->stream, ctx->ds, pb,
+                                                                 ps, b, p->max_depth, gs);
+            return 0;
+          });
+        });
       }
       if (want_timing) RT_HIP(ctx, stamp());
       // every 8 bounces look at the live count: stop when no path is left and
@@ -1062,7 +1126,15 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* scene) {
   {
     uint32_t budget = 27u * 1024u;
     if (const char* e = getenv("MI355RT_LDS_BYTES")) budget = (uint32_t)strtoul(e, nullptr, 10);
-    ctx->lds = plan_lds(f, kBlock, std::min(budget, 160u * 1024u - 13u * 1024u));
+    // LDS stack entries per lane; what a deeper hierarchy can need beyond them lives in global
+    // memory.  33 keeps a 512-thread workgroup's stack within its half of the CU's LDS; a lower
+    // cap buys LDS for more records but measured slower (book2: 41.6 ms at 16 against 39.5 ms).
+    uint32_t stack_cap = 33u;
+    if (const char* e = getenv("MI355RT_STACK_CAP")) stack_cap = (uint32_t)strtoul(e, nullptr, 10);
+    ctx->blocks_per_cu = 16u;
+    if (const char* e = getenv("MI355RT_BLOCKS_PER_CU"))
+      ctx->blocks_per_cu = std::max(1u, (uint32_t)strtoul(e, nullptr, 10));
+    ctx->lds = plan_lds(f, kBlock, std::min(budget, 160u * 1024u - 13u * 1024u), stack_cap);
     if (const char* e = getenv("MI355RT_LDS_PRIMS")) {
       LdsLayout& l = ctx->lds;
       uint32_t n = std::min<uint32_t>(l.n_prims, (uint32_t)strtoul(e, nullptr, 10));
@@ -1080,26 +1152,30 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* scene) {
     uint32_t tbudget = (160u * 1024u) / (1024u / tb) - stage_bytes - 1024u;
     if (const char* e = getenv("MI355RT_TRACE_LDS_BYTES")) tbudget = (uint32_t)strtoul(e, nullptr, 10);
     tbudget = std::min(tbudget, 160u * 1024u - stage_bytes - 512u);
-    ctx->lds_trace = plan_lds(f, tb, tbudget);
+    ctx->lds_trace = plan_lds(f, tb, tbudget, stack_cap);
     ctx->trace_blocks_per_cu = 4096u / tb;
     if (const char* e = getenv("MI355RT_TRACE_BLOCKS_PER_CU"))
       ctx->trace_blocks_per_cu = std::max(1u, (uint32_t)strtoul(e, nullptr, 10));
+    // overflow area for the stack entries LDS does not hold: one column per thread of the
+    // largest grid any traversal kernel is launched with
+    ctx->stack_overflow.release();
+    const uint32_t need = std::max(f.stack_entries + 1u, 2u);
+    if (need > ctx->lds.stack_depth) {
+      const uint32_t threads = ctx->n_cus * std::max(ctx->blocks_per_cu * (uint32_t)kBlock,
+                                                     ctx->trace_blocks_per_cu * tb);
+      const size_t words = (size_t)(need - ctx->lds.stack_depth) * threads;
+      RT_HIP(ctx, hipMalloc((void**)&ctx->stack_overflow.p, words * sizeof(uint32_t)));
+      ctx->stack_overflow.n = words;
+      ctx->lds.overflow = ctx->lds_trace.overflow = ctx->stack_overflow.p;
+      ctx->lds.overflow_stride = ctx->lds_trace.overflow_stride = threads;
+    }
   }
   if (getenv("MI355RT_DEBUG"))
     fprintf(stderr, "mi355rt: %zu records, %zu leaf slots, stack %u; extend LDS %u B (%u records, %u slots); "
             "trace block %u LDS %u B (%u records, %u slots)\n", f.nodes.size(), f.prims.size(),
             f.stack_entries, ctx->lds.bytes, ctx->lds.n_nodes, ctx->lds.n_prims, ctx->trace_block,
             ctx->lds_trace.bytes, ctx->lds_trace.n_nodes, ctx->lds_trace.n_prims);
-  if (ctx->lds.bytes > 32u * 1024u) {
-    int bytes = (int)ctx->lds.bytes;
-    const hipFuncAttribute attr = hipFuncAttributeMaxDynamicSharedMemorySize;
-    RT_HIP(ctx, hipFuncSetAttribute((const void*)extend_kernel<false, false>, attr, bytes));
-    RT_HIP(ctx, hipFuncSetAttribute((const void*)extend_kernel<false, true>, attr, bytes));
-    RT_HIP(ctx, hipFuncSetAttribute((const void*)extend_kernel<true, false>, attr, bytes));
-    RT_HIP(ctx, hipFuncSetAttribute((const void*)extend_kernel<true, true>, attr, bytes));
-    RT_HIP(ctx, hipFuncSetAttribute((const void*)first_hit_kernel<false>, attr, bytes));
-    RT_HIP(ctx, hipFuncSetAttribute((const void*)first_hit_kernel<true>, attr, bytes));
-  }
+  if (ctx->lds.bytes > 32u * 1024u) RT_HIP(ctx, allow_extend_lds((int)ctx->lds.bytes));
   if (ctx->lds_trace.bytes > 32u * 1024u) {
     int bytes = (int)ctx->lds_trace.bytes;
     RT_HIP(ctx, ctx->trace_block == 1024 ? allow_trace_lds<1024>(bytes)
@@ -1176,12 +1252,14 @@ int rt_first_hit(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_window* 
   if (e == hipSuccess) e = hipMalloc((void**)&d_t, n * sizeof(double));
   if (e == hipSuccess) e = hipMalloc((void**)&d_n, n * 3 * sizeof(double));
   if (e == hipSuccess) {
-    if (ctx->flat.chain_ranges.empty())
-      first_hit_kernel<false><<<blocks_for(n), kBlock, ctx->lds.bytes, ctx->stream>>>(ctx->ds, ctx->lds, ps,
-                                                                                      d_id, d_t, d_n);
-    else
-      first_hit_kernel<true><<<blocks_for(n), kBlock, ctx->lds.bytes, ctx->stream>>>(ctx->ds, ctx->lds, ps,
-                                                                                     d_id, d_t, d_n);
+    const uint32_t fgrid = std::min(blocks_for(n), ctx->n_cus * ctx->blocks_per_cu);
+    with_bool(!ctx->flat.chain_ranges.empty(), [&](auto C) {
+      return with_bool(ctx->lds.overflow != nullptr, [&](auto O) {
+        first_hit_kernel<decltype(C)::value, decltype(O)::value>
+            <<<fgrid, kBlock, ctx->lds.bytes, ctx->stream>>>(ctx->ds, ctx->lds, ps, d_id, d_t, d_n);
+        return 0;
+      });
+    });
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -1254,6 +1332,7 @@ void rt_destroy(rt_ctx* ctx) {
   ctx->images.release();
   ctx->texels.release();
   ctx->chain_boxes.release();
+  ctx->stack_overflow.release();
   ctx->chain_ranges.release();
   ctx->accum.release();
   ctx->stats.release();

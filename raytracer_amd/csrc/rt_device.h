@@ -441,9 +441,14 @@ struct Closest {
 struct LdsLayout {
   uint32_t n_nodes;      // nodes [0, n_nodes) are in LDS
   uint32_t n_prims;      // leaf slots [0, n_prims) are in LDS
-  uint32_t stack_depth;  // stack entries per lane
+  uint32_t stack_depth;  // stack entries per lane held in LDS
   uint32_t bytes;        // total dynamic LDS bytes per workgroup
   uint32_t entry_bits;   // bits of a traversal entry code (see entry_code_bits)
+  // Hierarchies whose worst-case stack need exceeds stack_depth: entries from index
+  // stack_depth on live in global memory, overflow[(index - stack_depth) * overflow_stride +
+  // global thread id].  Null when the whole stack fits in LDS.
+  uint32_t* overflow;
+  uint32_t overflow_stride;  // threads the overflow area was sized for (a launch has no more)
 };
 // The pointers carry the LDS address space: a generic pointer that may be LDS or
 // global turns every access into a flat instruction, several times slower to
@@ -456,6 +461,9 @@ struct LdsScene {
   const lds_f32x4* prims;  // the first 3 x 16 bytes of each DPrim
   lds_u32* stack;          // this lane's column of packed entries, `stack_stride` words apart
   uint32_t n_nodes, n_prims, stack_stride, entry_bits;
+  uint32_t stack_cap;      // entries of the column that exist in LDS
+  uint32_t* overflow;      // this lane's column of the global overflow area, or null (uniform)
+  uint32_t overflow_stride;
 };
 
 // Carve the workgroup's dynamic LDS and stage the scene head into it.  Every
@@ -478,6 +486,9 @@ RT_DEV LdsScene lds_stage(const DeviceScene& sc, const LdsLayout& lay, char* sme
   l.n_prims = lay.n_prims;
   l.stack_stride = block;
   l.entry_bits = lay.entry_bits;
+  l.stack_cap = lay.stack_depth;
+  l.overflow = lay.overflow ? lay.overflow + (blockIdx.x * block + tid) : nullptr;
+  l.overflow_stride = lay.overflow_stride;
   return l;
 }
 
@@ -635,8 +646,9 @@ RT_HD uint32_t stack_t_bits(float t, uint32_t bits) {
 }
 
 // MEDIA: constant media are tested (else skipped); CHAINS: records tied to the reference's
-// box chain are checked against it.
-template <bool STATS, bool MEDIA, bool CHAINS = MEDIA>
+// box chain are checked against it; OVERFLOW: the hierarchy can need more stack entries than
+// LDS holds per lane, the rest live in the global overflow area.
+template <bool STATS, bool MEDIA, bool CHAINS, bool OVERFLOW>
 RT_DEV Closest closest_hit(const DeviceScene& sc, const LdsScene& lds, V3 o, V3 d, double time,
                            double tmin, const DrawKey& key, Stats& st) {
   lds_u32* stack = lds.stack;
@@ -661,12 +673,25 @@ RT_DEV Closest closest_hit(const DeviceScene& sc, const LdsScene& lds, V3 o, V3 
   const f32x4* gnodes = (const f32x4*)sc.nodes;
   uint32_t sp = 0;
   uint32_t cur = sc.root_code;  // the root's own box is not tested
+  // stack slot access
+  uint32_t* const overflow = lds.overflow;
+  const uint32_t cap = lds.stack_cap, ostride = lds.overflow_stride;
+  auto put = [&](uint32_t pos, uint32_t word) {
+    if (!OVERFLOW || pos < cap)
+      stack[pos * stride] = word;
+    else
+      overflow[(size_t)(pos - cap) * ostride] = word;
+  };
+  auto get = [&](uint32_t pos) -> uint32_t {
+    if (!OVERFLOW || pos < cap) return stack[pos * stride];
+    return overflow[(size_t)(pos - cap) * ostride];
+  };
 
   // next entry from the stack that can still matter, or kNoEntry
   auto pop = [&]() -> uint32_t {
     while (sp) {
       RT_LP(st, LP_POP);
-      uint32_t w = stack[(--sp) * stride];
+      uint32_t w = get(--sp);
       if (__uint_as_float((w >> ebits) << (ebits - 1u)) <= best32w) return w & emask;
     }
     return kNoEntry;
@@ -719,11 +744,11 @@ RT_DEV Closest closest_hit(const DeviceScene& sc, const LdsScene& lds, V3 o, V3 
         w[3] = b3;
       }
       // stack the far hits, farthest first; a miss is overwritten by the next store
-      stack[sp * stride] = w[3];
+      put(sp, w[3]);
       sp += w[3] != kNoEntry ? 1u : 0u;
-      stack[sp * stride] = w[2];
+      put(sp, w[2]);
       sp += w[2] != kNoEntry ? 1u : 0u;
-      stack[sp * stride] = w[1];
+      put(sp, w[1]);
       sp += w[1] != kNoEntry ? 1u : 0u;
       cur = w[0] != kNoEntry ? (w[0] & emask) : pop();
     }

@@ -156,6 +156,23 @@ def test_stats_match_flat_oracle(gpu_ctx, golden_dir):
     assert list(st[:16]) == list(rs[:16])
 
 
+@pytest.mark.parametrize("name", ["book_cover", "book2"])
+def test_stack_overflow_area_gives_the_same_image(gpu_ctx, golden_dir, name, monkeypatch):
+    """With almost no LDS stack, nearly every stacked entry goes through the global overflow area."""
+    scene, g = load(golden_dir, name)
+    w, h = scene.width, scene.height
+    gpu_ctx.upload(scene)
+    want = gpu_ctx.render(gpu_ctx.params(w, h, 0, 3, 50, seed=2), dtype=np.float64)
+    want_ids = gpu_ctx.first_hit(w, h)[0]
+    monkeypatch.setenv("MI355RT_STACK_CAP", "3")
+    gpu_ctx.upload(scene)
+    got = gpu_ctx.render(gpu_ctx.params(w, h, 0, 3, 50, seed=2), dtype=np.float64)
+    got_ids = gpu_ctx.first_hit(w, h)[0]
+    monkeypatch.delenv("MI355RT_STACK_CAP")
+    gpu_ctx.upload(scene)
+    assert np.array_equal(want, got) and np.array_equal(want_ids, got_ids)
+
+
 def test_degenerate_requests(gpu_ctx, golden_dir):
     """No objects, no samples, no depth: what main.rs:82-101 would produce for them."""
     from raytracer_amd.scene import HostScene
