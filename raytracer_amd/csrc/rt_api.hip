@@ -415,17 +415,22 @@ RT_DEV void wave_flush(const uint32_t* stage, uint32_t n, uint32_t* g_counter, u
   wave_lds_sync();
 }
 
-template <int BLOCK, bool STATS, bool MEDIA, bool OVERFLOW>
+// TAIL: once few paths are left, a launch costs more than its rays (a wave needs tens of
+// microseconds for one bounce however empty the chip is).  The tail variant takes the queue
+// of bounce `bounce` and carries each wave's 64 paths through all remaining bounces in
+// place, dead lanes idle: one launch instead of one per bounce.
+template <int BLOCK, bool STATS, bool MEDIA, bool OVERFLOW, bool TAIL>
 __global__ void __launch_bounds__(BLOCK, 4)  // registers for four waves per SIMD
-trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_t bounce,
+trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_t first_bounce,
              uint32_t max_depth, unsigned long long* g_stats) {
   extern __shared__ __align__(16) char smem[];
   __shared__ uint32_t s_next[(BLOCK / 64) * kWaveStage];
-  const uint32_t* live = pb.live[bounce & 1u];
-  uint32_t* next_live = pb.live[(bounce + 1u) & 1u];
-  uint32_t* counters = pb.counters + (size_t)bounce * kCounterStride;
-  const uint32_t n_live =
-      bounce == 0 ? ps.n_paths : pb.counters[(size_t)(bounce - 1) * kCounterStride + 6];
+  const uint32_t* live = pb.live[first_bounce & 1u];
+  uint32_t* next_live = pb.live[(first_bounce + 1u) & 1u];
+  uint32_t* counters = pb.counters + (size_t)first_bounce * kCounterStride;
+  const uint32_t n_live = first_bounce == 0
+                              ? ps.n_paths
+                              : pb.counters[(size_t)(first_bounce - 1) * kCounterStride + 6];
   if (blockIdx.x * (uint32_t)BLOCK >= n_live) return;
   const LdsScene lds = lds_stage(sc, lay, smem, threadIdx.x, BLOCK);  // the only workgroup barrier
   uint32_t* stage = s_next + (threadIdx.x / 64u) * kWaveStage;
@@ -436,91 +441,102 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
   // a wave's 64 rays per trip; the trip count differs between the waves of a workgroup
   for (uint32_t base = blockIdx.x * (uint32_t)BLOCK + (threadIdx.x & ~63u); base < n_live;
        base += stride) {
-    uint32_t i = base + (threadIdx.x & 63u);
+    const uint32_t i = base + (threadIdx.x & 63u);
     bool valid = i < n_live;
-    bool survives = false;
     uint32_t path = 0;
-    DrawKey key{ps.seed, 0u, 0u, bounce};
-    ShadeOut so;
-    so.needs_vector = false;
-    if (valid) {
-      path = bounce == 0 ? i : live[i];
-      uint32_t s_local = path / ps.n_pixels, local = path % ps.n_pixels;
-      uint32_t x = ps.x0 + local % ps.ww, y = ps.y0 + local / ps.ww;
-      key.pixel = y * ps.width + x;
-      key.sample = ps.sample_base + s_local;
-      V3 o, d;
-      double time;
-      // the first bounce makes its own camera ray
-      if (bounce == 0) {
-        camera_ray(sc, ps, x, y, key, o, d, time);
-      } else {
-        double4 ro = pb.ray_o[path];
-        double4 rdv = pb.ray_d[path];
-        o = v3(ro.x, ro.y, ro.z);
-        d = v3(rdv.x, rdv.y, rdv.z);
-        time = ro.w;
-      }
-      stat<STATS>(st, RT_STAT_RAYS);
-      RT_LP(st, LP_RAY);
-      Closest h = closest_hit<STATS, MEDIA, MEDIA, OVERFLOW>(sc, lds, o, d, time, 0.001, key, st);
-      // ... and starts from beta = 1, L = 0
-      V3 beta = v3(1.0, 1.0, 1.0);
-      if (bounce != 0) {
-        double4 bt = pb.beta[path];
-        beta = v3(bt.x, bt.y, bt.z);
-      }
-      V3 add = v3(0.0, 0.0, 0.0);
-      bool adds = false;
-      if (h.item == kNoPrim) {
-        // miss: the recursion returns `background` (main.rs:137-139)
-        stat<STATS>(st, RT_STAT_SHADE_MISS);
-        add = vmul(beta, v3(sc.bg));
-        adds = true;
-      } else {
-        stat<STATS>(st, RT_STAT_HITS);
-        RT_LP(st, LP_SHADE);
-        const DPrim pr = load_prim<true>(sc, lds, h.item);
-        so = shade_begin<STATS, true>(sc, (h.kind >> 8) & 7u, pr, o, d, time, h.t, key, st);
-        if (so.emits) {
-          add = vmul(beta, so.emitted);
+    if (valid) path = first_bounce == 0 ? i : live[i];
+    uint32_t bounce = first_bounce;
+    bool survives;
+    do {
+      survives = false;
+      DrawKey key{ps.seed, 0u, 0u, bounce};
+      ShadeOut so;
+      so.needs_vector = false;
+      if (valid) {
+        uint32_t s_local = path / ps.n_pixels, local = path % ps.n_pixels;
+        uint32_t x = ps.x0 + local % ps.ww, y = ps.y0 + local / ps.ww;
+        key.pixel = y * ps.width + x;
+        key.sample = ps.sample_base + s_local;
+        V3 o, d;
+        double time;
+        // the first bounce makes its own camera ray
+        if (bounce == 0) {
+          camera_ray(sc, ps, x, y, key, o, d, time);
+        } else {
+          double4 ro = pb.ray_o[path];
+          double4 rdv = pb.ray_d[path];
+          o = v3(ro.x, ro.y, ro.z);
+          d = v3(rdv.x, rdv.y, rdv.z);
+          time = ro.w;
+        }
+        stat<STATS>(st, RT_STAT_RAYS);
+        RT_LP(st, LP_RAY);
+        Closest h = closest_hit<STATS, MEDIA, MEDIA, OVERFLOW>(sc, lds, o, d, time, 0.001, key, st);
+        // ... and starts from beta = 1, L = 0
+        V3 beta = v3(1.0, 1.0, 1.0);
+        if (bounce != 0) {
+          double4 bt = pb.beta[path];
+          beta = v3(bt.x, bt.y, bt.z);
+        }
+        V3 add = v3(0.0, 0.0, 0.0);
+        bool adds = false;
+        if (h.item == kNoPrim) {
+          // miss: the recursion returns `background` (main.rs:137-139)
+          stat<STATS>(st, RT_STAT_SHADE_MISS);
+          add = vmul(beta, v3(sc.bg));
           adds = true;
+        } else {
+          stat<STATS>(st, RT_STAT_HITS);
+          RT_LP(st, LP_SHADE);
+          const DPrim pr = load_prim<true>(sc, lds, h.item);
+          so = shade_begin<STATS, true>(sc, (h.kind >> 8) & 7u, pr, o, d, time, h.t, key, st);
+          if (so.emits) {
+            add = vmul(beta, so.emitted);
+            adds = true;
+          }
+          // depth budget: the scattered ray of the last allowed hit returns black (main.rs:121-122)
+          survives = so.scattered && bounce + 1u < max_depth;
+          if (survives) {
+            // everything but the direction is known before the random vector
+            V3 nb = vmul(beta, so.attenuation);
+            pb.beta[path] = make_double4(nb.x, nb.y, nb.z, 0.0);
+            pb.ray_o[path] = make_double4(so.p.x, so.p.y, so.p.z, time);
+          }
         }
-        // depth budget: the scattered ray of the last allowed hit returns black (main.rs:121-122)
-        survives = so.scattered && bounce + 1u < max_depth;
-        if (survives) {
-          // everything but the direction is known before the random vector
-          V3 nb = vmul(beta, so.attenuation);
-          pb.beta[path] = make_double4(nb.x, nb.y, nb.z, 0.0);
-          pb.ray_o[path] = make_double4(so.p.x, so.p.y, so.p.z, time);
+        // L += add; the first bounce also starts every path's L
+        if (bounce == 0) {
+          pb.radiance[path] = make_double4(0.0 + add.x, 0.0 + add.y, 0.0 + add.z, 0.0);
+        } else if (adds) {
+          double4 L = pb.radiance[path];
+          pb.radiance[path] = make_double4(L.x + add.x, L.y + add.y, L.z + add.z, 0.0);
         }
       }
-      // L += add; the first bounce also starts every path's L
-      if (bounce == 0) {
-        pb.radiance[path] = make_double4(0.0 + add.x, 0.0 + add.y, 0.0 + add.z, 0.0);
-      } else if (adds) {
-        double4 L = pb.radiance[path];
-        pb.radiance[path] = make_double4(L.x + add.x, L.y + add.y, L.z + add.z, 0.0);
+      {  // whole waves: the lanes look for their random vectors together
+        // (the wave's part of the first two stack rows is idle between traversals)
+        V3 inside = wave_rand_in_unit_sphere(survives && so.needs_vector, key,
+                                             lds.stack - (threadIdx.x & 63u), BLOCK, st);
+        shade_finish(so, inside);
       }
-    }
-    {  // whole waves: the lanes look for their random vectors together
-      // (the wave's part of the first two stack rows is idle between traversals)
-      V3 inside = wave_rand_in_unit_sphere(survives && so.needs_vector, key,
-                                           lds.stack - (threadIdx.x & 63u), BLOCK, st);
-      shade_finish(so, inside);
-    }
-    if (survives)
-      pb.ray_d[path] = make_double4(so.direction.x, so.direction.y, so.direction.z, 0.0);
-    const unsigned long long mask = __ballot(survives);
-    if (survives)
-      stage[n_staged + (uint32_t)__popcll(mask & ((1ull << lane_id()) - 1ull))] = path;
-    n_staged += (uint32_t)__popcll(mask);
-    if (n_staged >= kWaveFlushAt) {
-      wave_flush(stage, n_staged, counters + 6, next_live);
-      n_staged = 0;
+      if (survives)
+        pb.ray_d[path] = make_double4(so.direction.x, so.direction.y, so.direction.z, 0.0);
+      if (TAIL) {
+        // the same lane reads its own stores back: program order, no fence needed
+        valid = survives;
+        ++bounce;
+      }
+    } while (TAIL && __ballot(valid) != 0ull);
+    if (!TAIL) {
+      const unsigned long long mask = __ballot(survives);
+      if (survives)
+        stage[n_staged + (uint32_t)__popcll(mask & ((1ull << lane_id()) - 1ull))] = path;
+      n_staged += (uint32_t)__popcll(mask);
+      if (n_staged >= kWaveFlushAt) {
+        wave_flush(stage, n_staged, counters + 6, next_live);
+        n_staged = 0;
+      }
     }
   }
-  if (n_staged) wave_flush(stage, n_staged, counters + 6, next_live);
+  if (!TAIL && n_staged) wave_flush(stage, n_staged, counters + 6, next_live);
   if (STATS) flush_stats(st, g_stats);
 }
 
@@ -673,6 +689,7 @@ struct rt_ctx {
   uint32_t trace_block = 256;   // threads per trace_kernel workgroup: 256, 512 or 1024
   uint32_t trace_blocks_per_cu = 16;
   uint32_t blocks_per_cu = 16;  // 256-thread workgroups per CU in a grid (extend, shade, first hit)
+  uint32_t tail_paths = 1u << 18;  // fused pipeline: at most this many live paths finish in one launch
   DeviceArray<uint32_t> stack_overflow;
   std::vector<hipEvent_t> events;  // RT_FLAG_TIMING: three per bounce (before extend, between, after shade)
 };
@@ -801,24 +818,27 @@ auto with_bool(bool v, F&& f) {
 }
 
 template <int BLOCK>
-void launch_trace_block(rt_ctx* ctx, bool stats, bool media, uint32_t grid, const PathBuffers& pb,
-                        const PassInfo& ps, uint32_t b, uint32_t max_depth, unsigned long long* gs) {
+void launch_trace_block(rt_ctx* ctx, bool stats, bool media, bool tail, uint32_t grid,
+                        const PathBuffers& pb, const PassInfo& ps, uint32_t b, uint32_t max_depth,
+                        unsigned long long* gs) {
   const LdsLayout& l = ctx->lds_trace;
   with_bool(stats, [&](auto S) {
     return with_bool(media, [&](auto M) {
       return with_bool(l.overflow != nullptr, [&](auto O) {
-        trace_kernel<BLOCK, decltype(S)::value, decltype(M)::value, decltype(O)::value>
-            <<<grid, BLOCK, l.bytes, ctx->stream>>>(ctx->ds, l, pb, ps, b, max_depth, gs);
-        return 0;
+        return with_bool(tail, [&](auto T) {
+          trace_kernel<BLOCK, decltype(S)::value, decltype(M)::value, decltype(O)::value,
+                       decltype(T)::value>
+              <<<grid, BLOCK, l.bytes, ctx->stream>>>(ctx->ds, l, pb, ps, b, max_depth, gs);
+          return 0;
+        });
       });
     });
   });
 }
-void launch_trace(rt_ctx* ctx, bool stats, bool media, uint32_t grid, const PathBuffers& pb,
+void launch_trace(rt_ctx* ctx, bool stats, bool media, bool tail, uint32_t grid, const PathBuffers& pb,
                   const PassInfo& ps, uint32_t b, uint32_t max_depth, unsigned long long* gs) {
-  if (ctx->trace_block == 1024) launch_trace_block<1024>(ctx, stats, media, grid, pb, ps, b, max_depth, gs);
-  else if (ctx->trace_block == 512) launch_trace_block<512>(ctx, stats, media, grid, pb, ps, b, max_depth, gs);
-  else launch_trace_block<256>(ctx, stats, media, grid, pb, ps, b, max_depth, gs);
+  if (ctx->trace_block == 512) launch_trace_block<512>(ctx, stats, media, tail, grid, pb, ps, b, max_depth, gs);
+  else launch_trace_block<256>(ctx, stats, media, tail, grid, pb, ps, b, max_depth, gs);
 }
 void launch_extend(rt_ctx* ctx, bool stats, bool media, uint32_t grid, const PathBuffers& pb,
                    const PassInfo& ps, uint32_t b, unsigned long long* gs) {
@@ -838,13 +858,16 @@ template <int BLOCK>
 hipError_t allow_trace_lds(int bytes) {
   const hipFuncAttribute attr = hipFuncAttributeMaxDynamicSharedMemorySize;
   hipError_t e = hipSuccess;
-  for (int v = 0; v < 8 && e == hipSuccess; ++v)
+  for (int v = 0; v < 16 && e == hipSuccess; ++v)
     e = with_bool(v & 1, [&](auto S) {
       return with_bool(v & 2, [&](auto M) {
         return with_bool(v & 4, [&](auto O) {
-          return hipFuncSetAttribute(
-              (const void*)trace_kernel<BLOCK, decltype(S)::value, decltype(M)::value, decltype(O)::value>,
-              attr, bytes);
+          return with_bool(v & 8, [&](auto T) {
+            return hipFuncSetAttribute(
+                (const void*)trace_kernel<BLOCK, decltype(S)::value, decltype(M)::value,
+                                          decltype(O)::value, decltype(T)::value>,
+                attr, bytes);
+          });
         });
       });
     });
@@ -970,7 +993,7 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats) {
       if (want_timing) RT_HIP(ctx, stamp());
       if (fused) {
         // cheap shading: traversal and scatter in one kernel per bounce
-        launch_trace(ctx, want_stats, media, tgrid, pb, ps, b, p->max_depth, gs);
+        launch_trace(ctx, want_stats, media, false, tgrid, pb, ps, b, p->max_depth, gs);
         if (want_timing) RT_HIP(ctx, stamp());
       } else {
         launch_extend(ctx, want_stats, media, grid, pb, ps, b, gs);
@@ -995,6 +1018,16 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats) {
         if (live == 0) break;
         grid = std::max(1u, std::min(blocks_for(live), max_grid));
         tgrid = std::max(1u, trace_blocks_for(live));
+        if (fused && live <= ctx->tail_paths) {
+          // few paths left: all remaining bounces in one launch
+          if (want_timing) RT_HIP(ctx, stamp());
+          launch_trace(ctx, want_stats, media, true, tgrid, pb, ps, b + 1, p->max_depth, gs);
+          if (want_timing) {
+            RT_HIP(ctx, stamp());
+            RT_HIP(ctx, stamp());
+          }
+          break;
+        }
       }
     }
     resolve_kernel<<<blocks_for(n_pix), kBlock, 0, ctx->stream>>>(pb, ps, ctx->accum.p);
@@ -1131,6 +1164,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* scene) {
     // cap buys LDS for more records but measured slower (book2: 41.6 ms at 16 against 39.5 ms).
     uint32_t stack_cap = 33u;
     if (const char* e = getenv("MI355RT_STACK_CAP")) stack_cap = (uint32_t)strtoul(e, nullptr, 10);
+    if (const char* e = getenv("MI355RT_TAIL_PATHS")) ctx->tail_paths = (uint32_t)strtoul(e, nullptr, 10);
     ctx->blocks_per_cu = 16u;
     if (const char* e = getenv("MI355RT_BLOCKS_PER_CU"))
       ctx->blocks_per_cu = std::max(1u, (uint32_t)strtoul(e, nullptr, 10));
@@ -1143,8 +1177,8 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* scene) {
     }
     uint32_t tb = 512u;
     if (const char* e = getenv("MI355RT_TRACE_BLOCK")) tb = (uint32_t)strtoul(e, nullptr, 10);
-    if (tb != 256u && tb != 512u && tb != 1024u)
-      return fail(ctx, RT_ERR_INVALID, "MI355RT_TRACE_BLOCK must be 256, 512 or 1024");
+    if (tb != 256u && tb != 512u)
+      return fail(ctx, RT_ERR_INVALID, "MI355RT_TRACE_BLOCK must be 256 or 512");
     ctx->trace_block = tb;
     // LDS of a CU split between the resident workgroups (4 waves per SIMD in all three cases),
     // minus the per-wave queue stages
@@ -1178,9 +1212,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* scene) {
   if (ctx->lds.bytes > 32u * 1024u) RT_HIP(ctx, allow_extend_lds((int)ctx->lds.bytes));
   if (ctx->lds_trace.bytes > 32u * 1024u) {
     int bytes = (int)ctx->lds_trace.bytes;
-    RT_HIP(ctx, ctx->trace_block == 1024 ? allow_trace_lds<1024>(bytes)
-                : ctx->trace_block == 512 ? allow_trace_lds<512>(bytes)
-                                          : allow_trace_lds<256>(bytes));
+    RT_HIP(ctx, ctx->trace_block == 512 ? allow_trace_lds<512>(bytes) : allow_trace_lds<256>(bytes));
   }
   ctx->have_scene = true;
   return RT_OK;
