@@ -173,6 +173,29 @@ def test_stack_overflow_area_gives_the_same_image(gpu_ctx, golden_dir, name, mon
     assert np.array_equal(want, got) and np.array_equal(want_ids, got_ids)
 
 
+def test_headline_size_properties(gpu_ctx, golden_dir):
+    """book_cover at 1920x1080, 1024 spp (the benchmark's workload): the sample range splits
+    additively, a window is the same numbers as that region of the frame, and the window equals
+    the CPU oracle bit for bit."""
+    scene, g = load(golden_dir, "book_cover")
+    w, h, spp = 1920, 1080, 1024
+    scene.set_image(w, h)
+    gpu_ctx.upload(scene)
+    depth = scene.max_depth
+    whole = gpu_ctx.render(gpu_ctx.params(w, h, 0, spp, depth, seed=1), dtype=np.float64)
+    lo = gpu_ctx.render(gpu_ctx.params(w, h, 0, spp // 2, depth, seed=1), dtype=np.float64)
+    hi = gpu_ctx.render(gpu_ctx.params(w, h, spp // 2, spp, depth, seed=1), dtype=np.float64)
+    assert np.abs(whole - (lo + hi)).max() <= 1e-12 * np.abs(whole).max()
+    assert np.isfinite(whole).all() and whole.min() >= 0.0
+    window = (928, 522, 64, 36)
+    part = gpu_ctx.render(gpu_ctx.params(w, h, 0, spp, depth, seed=1, window=window), dtype=np.float64)
+    x0, y0, ww, wh = window
+    assert np.array_equal(part, whole[y0:y0 + wh, x0:x0 + ww])
+    o = po.Oracle(scene.view_ptr)
+    ref = o.render(po.make_params(w, h, 0, spp, depth, 1, window=window), po.MODE_ITERATIVE, threads=8)
+    assert np.array_equal(part, ref)
+
+
 def test_degenerate_requests(gpu_ctx, golden_dir):
     """No objects, no samples, no depth: what main.rs:82-101 would produce for them."""
     from raytracer_amd.scene import HostScene
