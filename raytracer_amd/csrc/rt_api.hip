@@ -3,17 +3,28 @@
 // Wavefront organisation of the reference's render closure (src/main.rs:82-101):
 // a pass takes S samples of every pixel of the window as independent paths
 // (path = s_local * n_pixels + pixel, so a wave holds neighbouring pixels of one
-// sample).  Per pass:
-//   raygen   jitter + Camera::get_ray                    (main.rs:87-94, camera.rs:22-36)
+// sample).  Two pipelines produce the same numbers:
+//
+// fused (scenes whose textures are all SolidColor), per pass:
 //   repeat max_depth times (ray_color's recursion, main.rs:120-140, unrolled):
-//     extend   closest hit over the BVH, then each live path is appended to the
-//              bin of what it hit: miss, or one bin per material kind
-//     shade    walks the bins in order, so a wave shades one material kind:
-//              emitted, scatter, attenuation; surviving paths are appended to
-//              the next bounce's live queue
+//     trace    camera ray (first bounce: jitter + Camera::get_ray, main.rs:87-94,
+//              camera.rs:22-36) or ray load, closest hit over the BVH, hit record,
+//              emitted, scatter, attenuation; survivors go to the next live queue.
+//              Once few paths are left, one launch finishes all their bounces.
 //   resolve  per pixel, adds the S path radiances in sample order (main.rs:97)
-// Queue appends use one atomic per wave (ballot + popcount).  All queue sizes
-// live in device memory, so a pass runs without a host round trip.
+//
+// binned (any scene; forced by RT_FLAG_BINNED), per pass:
+//   raygen   jitter + Camera::get_ray
+//   repeat max_depth times:
+//     extend   closest hit, then each live path is appended to the bin of what it
+//              hit: miss, or one bin per material kind
+//     shade    one launch per bin, so a kernel carries one material's code:
+//              emitted, scatter, attenuation; survivors go to the next live queue
+//   resolve
+//
+// Queue appends are staged in LDS and reach the global queues in runs, one atomic
+// per run.  All queue sizes live in device memory; the host looks at the live
+// count every eighth bounce only to stop early and to shrink the grid.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
