@@ -196,6 +196,33 @@ def test_headline_size_properties(gpu_ctx, golden_dir):
     assert np.array_equal(part, ref)
 
 
+def test_command_line_renderer_end_to_end(gpu_ctx, tmp_path):
+    """scene.ron in, image.png and 'Done in' out (main.rs:49-115), against the library + host resolve."""
+    import io
+    import subprocess
+    from PIL import Image
+    from raytracer_amd import abi
+    from raytracer_amd.scene import HostScene, resolve_srgb8
+    import test_oracle_kat as kat
+    text = kat.SCENE_HEAD + ('Sphere(center: (0, 0, 0), radius: 1, material: Shared("mirror")),'
+                             'Sphere(center: (0, -101, 0), radius: 100, material: Shared("grey"))') + "\n  ]\n)"
+    ron = tmp_path / "scene.ron"
+    ron.write_text(text)
+    exe = os.path.join(os.path.dirname(abi.device_lib()._name), "raytracer")
+    out = tmp_path / "image.png"
+    r = subprocess.run([exe, str(ron), "--spp", "5", "--seed", "7", "--out", str(out)], capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "Done in" in r.stdout + r.stderr
+    got = np.asarray(Image.open(io.BytesIO(out.read_bytes())).convert("RGB"))
+    scene = HostScene.load_ron_text(text)
+    gpu_ctx.upload(scene)
+    sums = gpu_ctx.render(gpu_ctx.params(scene.width, scene.height, 0, 5, scene.max_depth, seed=7), dtype=np.float64)
+    assert np.array_equal(got, resolve_srgb8(sums, 5))
+    missing = subprocess.run([exe, str(tmp_path / "nope.ron")], capture_output=True, text=True, timeout=60)
+    assert missing.returncode != 0 and "Error" in missing.stderr
+
+
 def test_degenerate_requests(gpu_ctx, golden_dir):
     """No objects, no samples, no depth: what main.rs:82-101 would produce for them."""
     from raytracer_amd.scene import HostScene
