@@ -8,8 +8,9 @@ CXX ?= g++
 ARCH ?= gfx950
 LIBDIR := raytracer_amd/lib
 
-HOST_SRC := raytracer_amd/host/ron.cpp raytracer_amd/host/loader.cpp raytracer_amd/host/hostlib.cpp
-HOST_HDR := raytracer_amd/host/ron.h raytracer_amd/host/host_scene.h raytracer_amd/csrc/philox.h \
+HOST_SRC := raytracer_amd/host/ron.cpp raytracer_amd/host/loader.cpp raytracer_amd/host/hostlib.cpp \
+            raytracer_amd/host/jpeg.cpp
+HOST_HDR := raytracer_amd/host/ron.h raytracer_amd/host/host_scene.h raytracer_amd/host/jpeg.h raytracer_amd/csrc/philox.h \
             raytracer_amd/csrc/scene_validate.h include/mi355rt.h
 DEV_SRC := raytracer_amd/csrc/rt_api.hip raytracer_amd/csrc/bvh_build.cpp
 DEV_HDR := $(wildcard raytracer_amd/csrc/*.h) include/mi355rt.h

@@ -195,9 +195,9 @@ typedef struct rt_host_options {
   uint32_t max_depth;              /* 0 = keep */
 } rt_host_options;
 
-/* Image("x.jpg") textures (src/texture/image.rs:12-20) are read from a binary
- * PPM (P6) of the same stem: next to the scene file first, then in every
- * directory registered here (this build links no JPEG decoder). */
+/* Image("x.jpg") textures (src/texture/image.rs:12-20): the file itself when it is a
+ * baseline JPEG (next to the scene file, then in every directory registered here),
+ * else a binary PPM (P6) of the same stem in the same places. */
 int rt_host_add_asset_dir(const char* dir);
 /* Replaces SceneLoader::new(path).load() (src/scene/loader.rs:39-93). */
 int rt_host_load_ron(const char* path, const rt_host_options* opt, rt_host_scene** out);
@@ -226,6 +226,11 @@ void rt_host_resolve_srgb8(const double* rgb_sum, uint64_t n_pixels, uint32_t sa
 void rt_host_resolve_srgb8_f32(const float* rgb_sum, uint64_t n_pixels,
                                uint32_t samples_per_pixel, uint8_t* rgb8_out);
 /* RGB8 PNG, rows top to bottom (src/main.rs:103-112). */
+/* Baseline JPEG (8-bit Huffman, grey or YCbCr) to RGB8: the decoder behind Image("x.jpg")
+ * textures (src/texture/image.rs:12-20).  Call with rgb8 == NULL to learn the size;
+ * `capacity` is the size of rgb8 in bytes (width * height * 3 needed). */
+int rt_host_decode_jpeg(const uint8_t* data, uint64_t size, uint32_t* width, uint32_t* height,
+                        uint8_t* rgb8, uint64_t capacity);
 int rt_host_write_png(const char* path, uint32_t width, uint32_t height, const uint8_t* rgb8);
 /* "Done in ..." duration text (src/main.rs:146-165); returns bytes written. */
 int rt_host_human_duration(uint64_t millis, char* buf, size_t buf_len);

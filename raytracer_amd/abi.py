@@ -142,7 +142,7 @@ HOST_SYMBOLS = [
     "rt_host_add_asset_dir", "rt_host_load_ron", "rt_host_load_ron_text", "rt_host_save_frozen",
     "rt_host_load_frozen", "rt_host_generate_cover", "rt_host_set_image", "rt_host_scene_view",
     "rt_host_camera_desc", "rt_host_free", "rt_host_last_error", "rt_host_resolve_srgb8",
-    "rt_host_resolve_srgb8_f32", "rt_host_write_png", "rt_host_human_duration",
+    "rt_host_resolve_srgb8_f32", "rt_host_write_png", "rt_host_human_duration", "rt_host_decode_jpeg",
 ]
 DEVICE_SYMBOLS = [
     "rt_create", "rt_upload_scene", "rt_render", "rt_render_f64", "rt_render_device",
@@ -190,6 +190,8 @@ def host_lib():
     L.rt_host_resolve_srgb8_f32.restype = None
     L.rt_host_write_png.argtypes = [cp, C.c_uint32, C.c_uint32, vp]
     L.rt_host_human_duration.argtypes = [C.c_uint64, cp, C.c_size_t]
+    L.rt_host_decode_jpeg.argtypes = [vp, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), vp,
+                                      C.c_uint64]
     _host = L
     return L
 

@@ -11,6 +11,7 @@
 
 #include "../csrc/scene_validate.h"
 #include "host_scene.h"
+#include "jpeg.h"
 
 namespace {
 
@@ -353,6 +354,22 @@ void rt_host_resolve_srgb8_f32(const float* rgb_sum, uint64_t n_pixels,
                                uint32_t samples_per_pixel, uint8_t* rgb8_out) {
   double scale = 1.0 / (double)samples_per_pixel;
   for (uint64_t i = 0; i < n_pixels * 3; ++i) rgb8_out[i] = to_u8((double)rgb_sum[i], scale);
+}
+
+int rt_host_decode_jpeg(const uint8_t* data, uint64_t size, uint32_t* width, uint32_t* height,
+                        uint8_t* rgb8, uint64_t capacity) {
+  if (!data || !width || !height) return set_error(RT_ERR_INVALID, "null argument");
+  std::vector<uint8_t> rgb;
+  std::string err;
+  uint32_t w = 0, h = 0;
+  if (!rt::decode_jpeg(data, (size_t)size, w, h, rgb, err)) return set_error(RT_ERR_UNSUPPORTED, err);
+  *width = w;
+  *height = h;
+  if (rgb8) {
+    if (capacity < rgb.size()) return set_error(RT_ERR_INVALID, "output buffer too small");
+    std::memcpy(rgb8, rgb.data(), rgb.size());
+  }
+  return RT_OK;
 }
 
 int rt_host_write_png(const char* path, uint32_t width, uint32_t height, const uint8_t* rgb8) {

@@ -8,12 +8,15 @@
 #include <cmath>
 #include <cstring>
 #include <fstream>
+#include <iterator>
 #include <map>
 #include <sstream>
 #include <stdexcept>
 
 #include "../csrc/philox.h"
 #include "host_scene.h"
+#include "jpeg.h"
+#include "jpeg.h"
 #include "ron.h"
 
 void rt_host_scene::refresh_view() {
@@ -409,25 +412,45 @@ class Loader {
     }
     for (const auto& d : AssetDirs::list()) candidates.push_back(d + "/" + stem + ".ppm");
 
+    // the file itself when it is a baseline JPEG, else an already decoded PPM next to it
+    // or in an asset directory
+    std::vector<std::string> originals{adjusted};
+    for (const auto& d : AssetDirs::list()) originals.push_back(d + "/" + file);
+
     uint32_t w = 0, h = 0;
     std::vector<uint8_t> rgb;
     std::string err, tried;
-    for (const auto& c : candidates) {
-      if (read_ppm(c, w, h, rgb, err)) {
-        rt_image im{};
-        im.width = w;
-        im.height = h;
-        im.offset = scene_.texels.size();
-        scene_.texels.insert(scene_.texels.end(), rgb.begin(), rgb.end());
-        scene_.images.push_back(im);
-        uint32_t idx = (uint32_t)scene_.images.size() - 1;
-        image_cache_[rel] = idx;
-        return idx;
+    auto keep = [&]() {
+      rt_image im{};
+      im.width = w;
+      im.height = h;
+      im.offset = scene_.texels.size();
+      scene_.texels.insert(scene_.texels.end(), rgb.begin(), rgb.end());
+      scene_.images.push_back(im);
+      uint32_t idx = (uint32_t)scene_.images.size() - 1;
+      image_cache_[rel] = idx;
+      return idx;
+    };
+    for (const auto& c : originals) {
+      std::ifstream f(c, std::ios::binary);
+      if (!f) {
+        tried += (tried.empty() ? "" : ", ") + c;
+        continue;
       }
+      std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+      if (bytes.size() >= 2 && bytes[0] == 0xFF && bytes[1] == 0xD8) {
+        if (rt::decode_jpeg(bytes.data(), bytes.size(), w, h, rgb, err)) return keep();
+        tried += (tried.empty() ? "" : ", ") + c + " (" + err + ")";
+      } else {
+        tried += (tried.empty() ? "" : ", ") + c + " (not a JPEG)";
+      }
+    }
+    for (const auto& c : candidates) {
+      if (read_ppm(c, w, h, rgb, err)) return keep();
       tried += (tried.empty() ? "" : ", ") + c;
     }
     fail(at, "Adjusted original path " + rel + " to " + adjusted +
-                 ": no decoded PPM found (tried " + tried + ")");
+                 ": no baseline JPEG or decoded PPM found (tried " + tried + ")");
   }
 
   // realize_material (src/scene/loader.rs:313-354)

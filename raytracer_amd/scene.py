@@ -131,6 +131,17 @@ def write_png(path, rgb8):
     _check(abi.host_lib().rt_host_write_png(str(path).encode(), w, h, a.ctypes.data))
 
 
+def decode_jpeg(data):
+    """Baseline JPEG bytes -> (h, w, 3) uint8, with the decoder Image("x.jpg") textures go through."""
+    L = abi.host_lib()
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+    w, h = C.c_uint32(), C.c_uint32()
+    _check(L.rt_host_decode_jpeg(buf, len(data), C.byref(w), C.byref(h), None, 0))
+    out = np.empty((h.value, w.value, 3), dtype=np.uint8)
+    _check(L.rt_host_decode_jpeg(buf, len(data), C.byref(w), C.byref(h), out.ctypes.data, out.nbytes))
+    return out
+
+
 def human_duration(millis):
     buf = C.create_string_buffer(64)
     abi.host_lib().rt_host_human_duration(int(millis), buf, 64)

@@ -171,18 +171,89 @@ def test_human_duration_format():
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/scenes"), reason="reference tree not present")
-def test_every_reference_scene_loads(tmp_path):
-    import subprocess
-    import sys
-    from raytracer_amd.scene import add_asset_dir
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    subprocess.check_call([sys.executable, os.path.join(root, "tools", "decode_image.py"),
-                           "/root/reference/scenes/earthmap.jpg", str(tmp_path / "earthmap.ppm")],
-                          stdout=subprocess.DEVNULL)
-    add_asset_dir(tmp_path)
+def test_every_reference_scene_loads():
+    """(globe.ron and book2.ron read scenes/earthmap.jpg through the built-in baseline JPEG decoder)"""
     counts = {}
     for path in sorted(glob.glob("/root/reference/scenes/*.ron")):
         s = HostScene.load_ron(path, scene_seed=1)
         counts[os.path.basename(path)] = s.view.n_objects
     assert counts["book_cover.ron"] == 488 and counts["book2.ron"] == 10370
     assert counts["cornell.ron"] == 8 and counts["bvh_test.ron"] == 29791 and len(counts) == 12
+
+
+def _jpeg_bytes(img, **kw):
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.fromarray(img).save(buf, format="JPEG", **kw)
+    return buf.getvalue()
+
+
+def _smooth_image(h, w, grey=False):
+    y, x = np.mgrid[0:h, 0:w]
+    r = 128 + 100 * np.sin(x / 9.0) * np.cos(y / 7.0)
+    g = 128 + 90 * np.cos(x / 5.0 + y / 11.0)
+    b = 255.0 * x / w
+    a = np.stack([r, g, b], axis=-1).clip(0, 255).astype(np.uint8)
+    return a[..., 0].copy() if grey else a
+
+
+@pytest.mark.parametrize("shape,kw,tol", [
+    ((40, 56), dict(quality=92, subsampling=0), 3),            # 4:4:4, the sampling of earthmap.jpg
+    ((33, 47), dict(quality=85, subsampling=0), 3),            # sizes that are no multiple of 8
+    ((48, 64), dict(quality=90, subsampling=2), 4),            # 4:2:0: triangle-filtered chroma
+    ((48, 64), dict(quality=90, subsampling=1), 4),            # 4:2:2
+    ((45, 61), dict(quality=90, subsampling=2), 4),            # 4:2:0, odd size
+    ((37, 29), dict(quality=95), 3),                           # grey
+])
+def test_jpeg_decoder_agrees_with_another_decoder(shape, kw, tol):
+    """Decoders differ in IDCT rounding and chroma upsampling (src/texture/image.rs:12-20 uses the
+    image crate's own); against PIL's: a few levels, and the same picture on average."""
+    from PIL import Image
+    from raytracer_amd.scene import decode_jpeg
+    grey = "subsampling" not in kw
+    data = _jpeg_bytes(_smooth_image(*shape, grey=grey), **kw)
+    want = np.asarray(Image.open(io.BytesIO(data)).convert("RGB")).astype(int)
+    got = decode_jpeg(data).astype(int)
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= tol
+    assert np.abs(got - want).mean() < 1.0
+
+
+def test_jpeg_decoder_restart_intervals_and_refusals():
+    from PIL import Image
+    from raytracer_amd.abi import RtError
+    from raytracer_amd.scene import decode_jpeg
+    img = _smooth_image(64, 80)
+    plain = _jpeg_bytes(img, quality=90, subsampling=0)
+    try:
+        with_rst = _jpeg_bytes(img, quality=90, subsampling=0, restart_marker_blocks=3)
+    except TypeError:
+        with_rst = None
+    if with_rst is not None and b"\xff\xdd" in with_rst:
+        assert np.array_equal(decode_jpeg(with_rst), decode_jpeg(plain))
+    with pytest.raises(RtError):
+        decode_jpeg(_jpeg_bytes(img, quality=90, progressive=True))
+    with pytest.raises(RtError):
+        decode_jpeg(plain[:200])
+    with pytest.raises(RtError):
+        decode_jpeg(b"not a jpeg at all")
+
+
+def test_image_texture_loads_the_jpeg_itself(tmp_path):
+    """Image("x.jpg") reads x.jpg when it is a baseline JPEG (else x.ppm next to it)."""
+    from raytracer_amd.scene import decode_jpeg
+    img = _smooth_image(32, 64)
+    data = _jpeg_bytes(img, quality=92, subsampling=0)
+    (tmp_path / "tex.jpg").write_bytes(data)
+    (tmp_path / "scene.ron").write_text("""Scene(
+  image: (width: 16, height: 16, samples_per_pixel: 1, max_depth: 2),
+  camera: (look_from: (0, 0, 5), look_at: (0, 0, 0), vertical_fov: 30, aperture: 0),
+  background: (1, 1, 1),
+  materials: {},
+  objects: [ Sphere(center: (0, 0, 0), radius: 1, material: Lambertian(albedo: Image("tex.jpg"))) ]
+)""")
+    s = HostScene.load_ron(str(tmp_path / "scene.ron"))
+    v = s.view
+    assert v.n_images == 1 and v.images[0].width == 64 and v.images[0].height == 32
+    texels = np.ctypeslib.as_array(v.texels, shape=(v.n_texel_bytes,))
+    assert np.array_equal(texels.reshape(32, 64, 3), decode_jpeg(data))
