@@ -156,3 +156,18 @@ def test_flat_traversal_answers_to_the_reference_boxes_for_overhanging_cuboid_si
     assert not o.world_hit([2.5, 10, 0], [0, -1, 0]).hit or o.world_hit([2.5, 10, 0], [0, -1, 0]).object != 0
     h = o.world_hit([2.5, 10, 0], [-0.01, -1, 0])
     assert h.hit and h.object == 0 and h.t == 9.5
+
+
+@pytest.mark.parametrize("first_seed", [0, 40, 80])
+def test_flat_traversal_equals_reference_topology_on_random_scenes(first_seed):
+    """40 seeded random scenes per case: every primitive kind, nested wrappers, overhanging cuboid
+    sides, media, all materials; 1 to 300 objects (one or two leaf lists in the reference)."""
+    from random_scenes import random_scene
+    for seed in range(first_seed, first_seed + 40):
+        s = HostScene.load_ron_text(random_scene(seed))
+        nodes, items, _ = build_bvh(s)
+        o = po.Oracle(s.view_ptr)
+        p = po.make_params(s.width, s.height, 0, 2, s.max_depth, 5)
+        ref = o.render(p, po.MODE_ITERATIVE, threads=4)
+        flat = o.render(p, po.MODE_FLAT, bvh=(nodes, items), threads=4)
+        assert np.array_equal(ref, flat), f"seed {seed}"

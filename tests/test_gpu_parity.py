@@ -223,6 +223,30 @@ def test_command_line_renderer_end_to_end(gpu_ctx, tmp_path):
     assert missing.returncode != 0 and "Error" in missing.stderr
 
 
+@pytest.mark.parametrize("first_seed,textured", [(0, False), (30, False), (60, True)])
+def test_random_scenes_match_the_oracle(gpu_ctx, first_seed, textured):
+    """30 seeded random scenes per case against the reference-topology oracle: first hits exactly;
+    radiance bit for bit where no libm call is involved (no media, no checker/Perlin), 1e-9 else."""
+    from random_scenes import random_scene
+    from raytracer_amd.scene import HostScene
+    for seed in range(first_seed, first_seed + 30):
+        text = random_scene(seed, textured=textured)
+        scene = HostScene.load_ron_text(text)
+        gpu_ctx.upload(scene)
+        w, h = scene.width, scene.height
+        o = po.Oracle(scene.view_ptr)
+        ids, t, n = gpu_ctx.first_hit(w, h)
+        rid, rt_, rn = o.first_hit(w, h)
+        assert np.array_equal(ids, rid) and np.array_equal(t, rt_) and np.array_equal(n, rn), f"seed {seed}"
+        img = gpu_ctx.render(gpu_ctx.params(w, h, 0, 2, scene.max_depth, seed=5), dtype=np.float64)
+        ref = o.render(po.make_params(w, h, 0, 2, scene.max_depth, 5), po.MODE_ITERATIVE, threads=4)
+        if textured or "ConstantMedium" in text:
+            close = np.isclose(img, ref, rtol=1e-9, atol=1e-12)
+            assert close.mean() > 0.995, f"seed {seed}: {(~close).sum()} values differ"
+        else:
+            assert np.array_equal(img, ref), f"seed {seed}"
+
+
 def test_degenerate_requests(gpu_ctx, golden_dir):
     """No objects, no samples, no depth: what main.rs:82-101 would produce for them."""
     from raytracer_amd.scene import HostScene
