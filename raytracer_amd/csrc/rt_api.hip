@@ -59,10 +59,36 @@ struct PathBuffers {
   uint64_t capacity;
 };
 
+// Division of a 32-bit number by an invariant divisor as one multiply-high and two shifts
+// (Granlund and Montgomery, "Division by invariant integers using multiplication", fig. 4.1):
+// q = (t + ((n - t) >> s1)) >> s2 with t = mulhi(m, n).  Exact for every n < 2^32.
+struct FastDiv {
+  uint32_t d, m, s1, s2;
+};
+inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f{};
+  f.d = d;
+  uint32_t l = 0;
+  while (l < 32 && (1ull << l) < d) ++l;  // ceil(log2 d)
+  f.m = (uint32_t)((((1ull << l) - d) << 32) / d + 1);
+  f.s1 = l < 1 ? l : 1;
+  f.s2 = l > 1 ? l - 1 : 0;
+  return f;
+}
+__host__ __device__ inline uint32_t fastdiv(uint32_t n, const FastDiv& f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t t = __umulhi(f.m, n);
+#else
+  uint32_t t = (uint32_t)(((uint64_t)f.m * n) >> 32);
+#endif
+  return (t + ((n - t) >> f.s1)) >> f.s2;
+}
+
 struct PassInfo {
   uint32_t width, height;      // full image
   uint32_t x0, y0, ww, wh;     // window
   uint32_t n_pixels;           // ww * wh
+  FastDiv by_pixels, by_ww;    // division by n_pixels and by ww
   uint32_t n_paths;            // n_pixels * samples in this pass
   uint32_t sample_base;        // absolute index of the pass's first sample
   uint32_t first_pass;         // 1: resolve starts the sums
@@ -148,8 +174,9 @@ __global__ void __launch_bounds__(kBlock)
 raygen_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps) {
   uint32_t path = blockIdx.x * kBlock + threadIdx.x;
   if (path >= ps.n_paths) return;
-  uint32_t local = path % ps.n_pixels, s_local = path / ps.n_pixels;
-  uint32_t x = ps.x0 + local % ps.ww, y = ps.y0 + local / ps.ww;
+  uint32_t s_local = fastdiv(path, ps.by_pixels), local = path - s_local * ps.n_pixels;
+  uint32_t row = fastdiv(local, ps.by_ww);
+  uint32_t x = ps.x0 + (local - row * ps.ww), y = ps.y0 + row;
   DrawKey key{ps.seed, y * ps.width + x, ps.sample_base + s_local, 0u};
   V3 origin, dir;
   double time;
@@ -191,8 +218,9 @@ extend_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32
       path = bounce == 0 ? i : live[i];
       double4 ro = pb.ray_o[path];
       double4 rdv = pb.ray_d[path];
-      uint32_t s_local = path / ps.n_pixels, local = path % ps.n_pixels;
-      uint32_t x = ps.x0 + local % ps.ww, y = ps.y0 + local / ps.ww;
+      uint32_t s_local = fastdiv(path, ps.by_pixels), local = path - s_local * ps.n_pixels;
+      uint32_t row = fastdiv(local, ps.by_ww);
+      uint32_t x = ps.x0 + (local - row * ps.ww), y = ps.y0 + row;
       DrawKey key{ps.seed, y * ps.width + x, ps.sample_base + s_local, bounce};
       stat<STATS>(st, RT_STAT_RAYS);
       Closest h = closest_hit<STATS, MEDIA, MEDIA, OVERFLOW>(sc, lds, v3(ro.x, ro.y, ro.z), v3(rdv.x, rdv.y, rdv.z),
@@ -360,8 +388,9 @@ shade_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps, uint32_t bounce, uint3
         double4 ro = pb.ray_o[path];
         double4 rdv = pb.ray_d[path];
         const DPrim pr = sc.prims[pb.hit_item[path]];
-        uint32_t s_local = path / ps.n_pixels, local = path % ps.n_pixels;
-        uint32_t x = ps.x0 + local % ps.ww, y = ps.y0 + local / ps.ww;
+        uint32_t s_local = fastdiv(path, ps.by_pixels), local = path - s_local * ps.n_pixels;
+        uint32_t row = fastdiv(local, ps.by_ww);
+        uint32_t x = ps.x0 + (local - row * ps.ww), y = ps.y0 + row;
         key.pixel = y * ps.width + x;
         key.sample = ps.sample_base + s_local;
         so = shade_begin<STATS, SOLID>(sc, (uint32_t)BIN - 1u, pr, v3(ro.x, ro.y, ro.z),
@@ -464,8 +493,9 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
       ShadeOut so;
       so.needs_vector = false;
       if (valid) {
-        uint32_t s_local = path / ps.n_pixels, local = path % ps.n_pixels;
-        uint32_t x = ps.x0 + local % ps.ww, y = ps.y0 + local / ps.ww;
+        uint32_t s_local = fastdiv(path, ps.by_pixels), local = path - s_local * ps.n_pixels;
+        uint32_t row = fastdiv(local, ps.by_ww);
+        uint32_t x = ps.x0 + (local - row * ps.ww), y = ps.y0 + row;
         key.pixel = y * ps.width + x;
         key.sample = ps.sample_base + s_local;
         V3 o, d;
@@ -618,7 +648,8 @@ first_hit_kernel(DeviceScene sc, LdsLayout lay, PassInfo ps, uint32_t* id, doubl
 template <bool CHAINS, bool OVERFLOW>
 RT_DEV void first_hit_pixel(const DeviceScene& sc, const LdsScene& lds, const PassInfo& ps,
                             uint32_t local, uint32_t* id, double* t_out, double* normal) {
-  uint32_t x = ps.x0 + local % ps.ww, y = ps.y0 + local / ps.ww;
+  uint32_t row = fastdiv(local, ps.by_ww);
+  uint32_t x = ps.x0 + (local - row * ps.ww), y = ps.y0 + row;
   double u = ((double)x + 0.5) / ((double)ps.width - 1.0);
   double v = ((double)(ps.height - y) + 0.5) / ((double)ps.height - 1.0);
   const rt_camera& c = sc.cam;
@@ -795,6 +826,16 @@ int check_window(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_window* 
     ps.wh = win->h;
   }
   ps.n_pixels = ps.ww * ps.wh;
+  ps.by_pixels = make_fastdiv(ps.n_pixels);
+  ps.by_ww = make_fastdiv(ps.ww);
+  // the two divisors are checked on the values where a wrong multiplier would show first
+  for (const FastDiv* f : {&ps.by_pixels, &ps.by_ww})
+    for (uint64_t k : {(uint64_t)1, (uint64_t)2, (uint64_t)3, (uint64_t)(0xFFFFFFFFu / f->d)})
+      for (int64_t e = -1; e <= 1; ++e) {
+        uint64_t n = k * f->d + (uint64_t)e;
+        if (n <= 0xFFFFFFFFull && fastdiv((uint32_t)n, *f) != (uint32_t)(n / f->d))
+          return fail(ctx, RT_ERR_INVALID, "internal: invariant division check failed");
+      }
   return RT_OK;
 }
 
