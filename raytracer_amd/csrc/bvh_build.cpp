@@ -293,6 +293,7 @@ struct BinNode {
 
 struct Builder {
   uint32_t max_leaf = 2;
+  int n_bins = 16;  // SAH bins per axis
   std::vector<BuildItem>& items;
   std::vector<BinNode>& nodes;
   std::vector<uint32_t>& leaf_order;  // slots in leaf order
@@ -328,14 +329,15 @@ struct Builder {
     bool have_split = false;
 
     // binned SAH on the axis/plane with the lowest cost
-    const int kBins = 16;
+    const int kMaxBins = 128;
+    const int kBins = n_bins;
     double best_cost = INF;
     int best_axis = -1, best_plane = -1;
     for (int a = 0; a < 3; ++a) {
       double lo = cbounds.lo[a], hi = cbounds.hi[a];
       if (!(hi > lo) || !std::isfinite(lo) || !std::isfinite(hi)) continue;
-      Box bin_box[kBins];
-      size_t bin_count[kBins] = {0};
+      Box bin_box[kMaxBins];
+      size_t bin_count[kMaxBins] = {0};
       double scale = (double)kBins / (hi - lo);
       for (size_t i = begin; i < end; ++i) {
         int b = (int)((items[i].centroid[a] - lo) * scale);
@@ -343,8 +345,8 @@ struct Builder {
         bin_box[b].grow(items[i].box);
         bin_count[b]++;
       }
-      double right_area[kBins];
-      size_t right_count[kBins];
+      double right_area[kMaxBins];
+      size_t right_count[kMaxBins];
       Box acc;
       size_t cnt = 0;
       for (int b = kBins - 1; b > 0; --b) {
@@ -669,6 +671,10 @@ std::string flatten_scene(const rt_scene& s, FlatScene& out, int& code) {
     std::vector<uint32_t> leaf_order;
     leaf_order.reserve(build_items.size());
     Builder b(build_items, bin, leaf_order);
+    if (const char* e = getenv("MI355RT_SAH_BINS")) {
+      long v = strtol(e, nullptr, 10);
+      if (v >= 2 && v <= 128) b.n_bins = (int)v;
+    }
     if (const char* e = getenv("MI355RT_LEAF_ITEMS")) {
       unsigned long v = strtoul(e, nullptr, 10);
       if (v >= 1 && v <= kMaxLeafItems) b.max_leaf = (uint32_t)v;
