@@ -286,6 +286,7 @@ enum {
   RT_STAT_TEX_PERLIN,
   RT_STAT_TEX_IMAGE,
   RT_STAT_SPHERE_ROOTS,    /* sphere tests whose discriminant was >= 0 */
+  RT_STAT_NODE_VISITS,     /* interior records visited (each tests its 2-4 children) */
   RT_STAT_EXTEND_NS = 20,  /* RT_FLAG_TIMING: summed device time of the extend launches */
   RT_STAT_EXTEND_LAUNCHES = 21,
   RT_STAT_SHADE_NS = 22,

@@ -1171,6 +1171,7 @@ OptHit flat_hit(const SceneData& sc, const FlatBvh& bvh, const Ray& ray, Range t
     uint32_t next = 0;
     if (n.b & 0x80000000u) {
       uint32_t kids = (n.b & 3u) + 1u;
+      if (cx.count) cx.count->v[RT_STAT_NODE_VISITS]++;
       struct Hit {
         uint64_t key;
         Entry e;

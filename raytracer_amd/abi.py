@@ -14,7 +14,7 @@ STAT_NAMES = [
     "rays", "box_tests", "sphere_tests", "msphere_tests", "rect_tests", "medium_tests",
     "op_translate", "op_rotate", "hits", "shade_miss", "shade_lambertian", "shade_metal",
     "shade_dielectric", "shade_light", "shade_isotropic", "tex_checker", "tex_perlin", "tex_image",
-    "sphere_roots", "unused19", "extend_ns", "extend_launches", "shade_ns", "shade_launches",
+    "sphere_roots", "node_visits", "extend_ns", "extend_launches", "shade_ns", "shade_launches",
 ]
 RT_FLAG_STATS = 1
 RT_FLAG_TIMING = 2

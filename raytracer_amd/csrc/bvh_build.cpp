@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -39,9 +40,11 @@ struct Box {
       hi[a] = std::fmax(hi[a], p[a]);
     }
   }
-  void grow(const Box& b) {
-    grow(b.lo);
-    grow(b.hi);
+  void grow(const Box& b) {  // (an empty b, lo = +inf and hi = -inf, changes nothing)
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = std::fmin(lo[a], b.lo[a]);
+      hi[a] = std::fmax(hi[a], b.hi[a]);
+    }
   }
   double area() const {
     double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
@@ -293,7 +296,8 @@ struct BinNode {
 
 struct Builder {
   uint32_t max_leaf = 2;
-  int n_bins = 16;  // SAH bins per axis
+  int n_bins = 32;  // SAH bins per axis
+  double min_side = 0.0;  // smallest share of the items a side of a split may get
   std::vector<BuildItem>& items;
   std::vector<BinNode>& nodes;
   std::vector<uint32_t>& leaf_order;  // slots in leaf order
@@ -362,6 +366,7 @@ struct Builder {
         lcnt += bin_count[b];
         size_t rcnt = right_count[b + 1];
         if (lcnt == 0 || rcnt == 0) continue;
+        if ((double)std::min(lcnt, rcnt) < min_side * (double)count) continue;
         if (!fits(lcnt, levels_left) || !fits(rcnt, levels_left)) continue;
         double cost = lacc.area() * (double)lcnt + right_area[b + 1] * (double)rcnt;
         if (cost < best_cost) {
@@ -671,6 +676,7 @@ std::string flatten_scene(const rt_scene& s, FlatScene& out, int& code) {
     std::vector<uint32_t> leaf_order;
     leaf_order.reserve(build_items.size());
     Builder b(build_items, bin, leaf_order);
+    if (const char* e = getenv("MI355RT_SAH_MIN_SIDE")) b.min_side = strtod(e, nullptr);
     if (const char* e = getenv("MI355RT_SAH_BINS")) {
       long v = strtol(e, nullptr, 10);
       if (v >= 2 && v <= 128) b.n_bins = (int)v;

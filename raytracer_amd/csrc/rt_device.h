@@ -717,7 +717,10 @@ RT_DEV Closest closest_hit(const DeviceScene& sc, const LdsScene& lds, V3 o, V3 
 #pragma unroll
         for (uint32_t k = 0; k < 8; ++k) r[k] = gnodes[2 * first + k];
       }
-      if (STATS) st.v[RT_STAT_BOX_TESTS] += n;
+      if (STATS) {
+        st.v[RT_STAT_BOX_TESTS] += n;
+        st.v[RT_STAT_NODE_VISITS]++;
+      }
       uint32_t w[4];
 #pragma unroll
       for (uint32_t k = 0; k < 4; ++k) {

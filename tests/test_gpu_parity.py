@@ -147,13 +147,14 @@ def test_stats_match_flat_oracle(gpu_ctx, golden_dir):
     p2 = gpu_ctx.params(scene.width, scene.height, 0, 4, 50, seed=9, window=window,
                         flags=abi.RT_FLAG_BINNED)
     img2, st2 = gpu_ctx.render(p2, dtype=np.float64, stats=True)
-    assert np.array_equal(img, img2) and list(st[:19]) == list(st2[:19])
+    assert np.array_equal(img, img2) and list(st[:20]) == list(st2[:20])
     nodes, items, _ = build_bvh(scene)
     o = po.Oracle(scene.view_ptr)
     pi = po.make_params(scene.width, scene.height, 0, 4, 50, 9, window=window)
     ref, rs = o.render(pi, po.MODE_FLAT, bvh=(nodes, items), threads=2, stats=True)
     assert np.array_equal(img, ref)
     assert list(st[:16]) == list(rs[:16])
+    assert st[abi.STAT_NAMES.index("node_visits")] == rs[abi.STAT_NAMES.index("node_visits")] > 0
 
 
 @pytest.mark.parametrize("name", ["book_cover", "book2"])

@@ -15,6 +15,6 @@ ctx = Context(0); ctx.upload(scene)
 img, st = ctx.render(ctx.params(w, h, 0, spp, scene.max_depth, seed=1), dtype=np.float32, stats=True)
 rays = float(st[0])
 print(name, "nodes", len(nodes), "items", len(items), "depth", depth)
-for i, n in enumerate(abi.STAT_NAMES[:19]):
+for i, n in enumerate(abi.STAT_NAMES[:20]):
     if st[i]:
         print(f"  {n:18s} {int(st[i]):14d}  per ray {st[i] / rays:8.3f}")
