@@ -295,8 +295,9 @@ struct BinNode {
 };
 
 struct Builder {
-  uint32_t max_leaf = 2;
-  int n_bins = 32;  // SAH bins per axis
+  uint32_t max_leaf = 1;
+  int n_bins = 64;          // SAH bins per axis (ranges too large for the exact sweep)
+  size_t sweep_max = 4096;  // ranges up to this many items try every split position
   double min_side = 0.0;  // smallest share of the items a side of a split may get
   std::vector<BuildItem>& items;
   std::vector<BinNode>& nodes;
@@ -332,12 +333,53 @@ struct Builder {
     size_t mid = begin;
     bool have_split = false;
 
+    // small ranges: exact SAH, every split position of the centroid order on every axis
+    if (count <= sweep_max) {
+      double best_cost = INF;
+      int best_axis = -1;
+      size_t best_left = 0;
+      std::vector<double> right_area(count);
+      auto by_axis = [&](int a) {
+        std::stable_sort(items.begin() + (long)begin, items.begin() + (long)end,
+                         [a](const BuildItem& x, const BuildItem& y) {
+                           return x.centroid[a] < y.centroid[a];
+                         });
+      };
+      for (int a = 0; a < 3; ++a) {
+        if (!(cbounds.hi[a] > cbounds.lo[a])) continue;
+        by_axis(a);
+        Box acc;
+        for (size_t i = count; i-- > 1;) {
+          acc.grow(items[begin + i].box);
+          right_area[i] = acc.area();
+        }
+        Box lacc;
+        for (size_t l = 1; l < count; ++l) {  // l items on the left
+          lacc.grow(items[begin + l - 1].box);
+          size_t r = count - l;
+          if ((double)std::min(l, r) < min_side * (double)count) continue;
+          if (!fits(l, levels_left) || !fits(r, levels_left)) continue;
+          double cost = lacc.area() * (double)l + right_area[l] * (double)r;
+          if (cost < best_cost) {
+            best_cost = cost;
+            best_axis = a;
+            best_left = l;
+          }
+        }
+      }
+      if (best_axis >= 0) {
+        by_axis(best_axis);
+        mid = begin + best_left;
+        have_split = true;
+      }
+    }
+
     // binned SAH on the axis/plane with the lowest cost
     const int kMaxBins = 128;
     const int kBins = n_bins;
     double best_cost = INF;
     int best_axis = -1, best_plane = -1;
-    for (int a = 0; a < 3; ++a) {
+    for (int a = 0; a < 3 && !have_split && count > sweep_max; ++a) {
       double lo = cbounds.lo[a], hi = cbounds.hi[a];
       if (!(hi > lo) || !std::isfinite(lo) || !std::isfinite(hi)) continue;
       Box bin_box[kMaxBins];
@@ -681,6 +723,7 @@ std::string flatten_scene(const rt_scene& s, FlatScene& out, int& code) {
       long v = strtol(e, nullptr, 10);
       if (v >= 2 && v <= 128) b.n_bins = (int)v;
     }
+    if (const char* e = getenv("MI355RT_SAH_SWEEP")) b.sweep_max = strtoul(e, nullptr, 10);
     if (const char* e = getenv("MI355RT_LEAF_ITEMS")) {
       unsigned long v = strtoul(e, nullptr, 10);
       if (v >= 1 && v <= kMaxLeafItems) b.max_leaf = (uint32_t)v;
