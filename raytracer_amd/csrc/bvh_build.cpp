@@ -562,6 +562,7 @@ std::string flatten_scene(const rt_scene& s, FlatScene& out, int& code) {
     bool textured = m.kind == RT_MAT_LAMBERTIAN || m.kind == RT_MAT_DIFFUSE_LIGHT ||
                     m.kind == RT_MAT_ISOTROPIC;
     d.needs_uv = textured ? tex_needs_uv[m.texture] : 0;
+    d.textured = textured && s.textures[m.texture].kind != RT_TEX_SOLID ? 1u : 0u;
     out.materials[i] = d;
   }
   out.perlin.assign(s.perlin, s.perlin + s.n_perlin);
@@ -652,6 +653,7 @@ std::string flatten_scene(const rt_scene& s, FlatScene& out, int& code) {
     }
     d.kind |= (m.kind & 7u) << 8;
     d.kind |= needs_uv << 11;
+    if (out.materials[p.material].textured) d.kind |= kTexturedBit;
     return d;
   };
 
@@ -671,6 +673,7 @@ std::string flatten_scene(const rt_scene& s, FlatScene& out, int& code) {
       DPrim d{};
       d.kind = DP_MEDIUM | ((uint32_t)RT_MAT_ISOTROPIC << 8);
       d.kind |= (out.materials[o.medium_material].needs_uv ? 1u : 0u) << 11;
+      if (out.materials[o.medium_material].textured) d.kind |= kTexturedBit;
       d.ops = pack_ops(o.first_op, o.op_count);
       d.material = o.medium_material;
       d.object = oi;

@@ -23,7 +23,8 @@ enum DPrimKind : uint32_t {
 //   kind word: bits 0-3 DPrimKind, bits 4-5 rect axis, bits 8-10 material kind
 //              (rt_material_kind) of `material`, bit 11 "texture needs (u,v)",
 //              bit 12 "a hit counts only if the ray passes the reference's box chain"
-//              (a cuboid side that sticks out of Cuboid::bounding_box, see FlatScene::chain_boxes).
+//              (a cuboid side that sticks out of Cuboid::bounding_box, see FlatScene::chain_boxes),
+//              bit 13 "the material's texture is not a SolidColor" (its shading is the costly kind).
 //   ops word : first op (low 24 bits) | op count (high 8 bits), outermost first.
 //   sphere        p = {cx, cy, cz, radius, -}
 //   moving sphere p = {c0x, c0y, c0z, radius, time0}, p5 = aux index; aux = {c1x, c1y, c1z, time1}
@@ -59,7 +60,7 @@ struct DMaterial {  // 48 bytes
   double albedo[3];
   double param;
   uint32_t needs_uv;
-  uint32_t pad;
+  uint32_t textured;  // reads a texture that is not a SolidColor
 };
 static_assert(sizeof(DMaterial) == 48, "DMaterial must be 48 bytes");
 
@@ -81,6 +82,7 @@ const uint32_t kMaxBvhDepth = 32;      // levels of the binary tree the wide one
 const uint32_t kMaxLeafItems = 8;     // upper bound; the builder's default is lower
 const uint32_t kNoPrim = 0xFFFFFFFFu;
 const uint32_t kChainBit = 1u << 12;
+const uint32_t kTexturedBit = 1u << 13;
 
 // Everything the device needs, still in host memory.
 struct FlatScene {

@@ -45,7 +45,8 @@ namespace {
 
 const int kBlock = 256;
 const uint32_t kBins = 1 + RT_MAT_KINDS;  // miss + one per material kind
-const uint32_t kCounterStride = 8;        // [0..5] bin sizes, [6] next live count
+const uint32_t kCounterStride = 8;        // [0..5] bin sizes, [6] next live count, [7] deferred hits
+const int kAnyBin = 7;                    // shade_kernel over the deferred queue: any material kind
 
 struct PathBuffers {
   double4* ray_o;     // origin xyz, time
@@ -54,7 +55,7 @@ struct PathBuffers {
   double4* radiance;  // running radiance
   uint32_t* hit_item; // leaf slot hit, or kNoPrim
   uint32_t* live[2];  // live-path queues, ping-pong
-  uint32_t* bins;     // kBins queues of `capacity` entries
+  uint32_t* bins;     // kBins queues of `capacity` entries (binned pipeline), or the one deferred queue
   uint32_t* counters; // (max_depth) x kCounterStride
   uint64_t capacity;
 };
@@ -343,7 +344,8 @@ RT_DEV void shade_finish(ShadeOut& out, V3 inside) {
 // One instantiation per bin (BIN 0 = misses, BIN 1 + k = material kind k), each
 // launched over its own queue: a kernel carries only its material's code and
 // registers.  SOLID: every texture of the scene is a SolidColor (no texture walk,
-// no (u, v)).
+// no (u, v)).  BIN kAnyBin: the queue of hits trace_kernel deferred (materials with
+// procedural or image textures, whatever their kind).
 template <int BIN, bool STATS, bool SOLID>
 __global__ void __launch_bounds__(kBlock)
 shade_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps, uint32_t bounce, uint32_t max_depth,
@@ -355,12 +357,12 @@ shade_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps, uint32_t bounce, uint3
   lds_u32* xch = (lds_u32*)s_xch + (threadIdx.x / 64u) * 128u;
   // material kinds whose scatter draws a random unit vector
   constexpr bool kVector = BIN == 1 + RT_MAT_LAMBERTIAN || BIN == 1 + RT_MAT_METAL ||
-                           BIN == 1 + RT_MAT_ISOTROPIC;
+                           BIN == 1 + RT_MAT_ISOTROPIC || BIN == kAnyBin;
   uint32_t* counters = pb.counters + (size_t)bounce * kCounterStride;
   uint32_t* next_live = pb.live[(bounce + 1u) & 1u];
   const uint32_t total = counters[BIN];
   if (blockIdx.x * kBlock >= total) return;
-  const uint32_t* queue = pb.bins + (size_t)BIN * pb.capacity;
+  const uint32_t* queue = pb.bins + (BIN == kAnyBin ? (size_t)0 : (size_t)BIN * pb.capacity);
   if (threadIdx.x == 0) s_next_count = 0;
   __syncthreads();
   Stats st;
@@ -393,7 +395,8 @@ shade_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps, uint32_t bounce, uint3
         uint32_t x = ps.x0 + (local - row * ps.ww), y = ps.y0 + row;
         key.pixel = y * ps.width + x;
         key.sample = ps.sample_base + s_local;
-        so = shade_begin<STATS, SOLID>(sc, (uint32_t)BIN - 1u, pr, v3(ro.x, ro.y, ro.z),
+        const uint32_t kind = BIN == kAnyBin ? (pr.kind >> 8) & 7u : (uint32_t)BIN - 1u;
+        so = shade_begin<STATS, SOLID>(sc, kind, pr, v3(ro.x, ro.y, ro.z),
                                        v3(rdv.x, rdv.y, rdv.z), ro.w, rdv.w, key, st);
         if (so.emits) {
           double4 L = pb.radiance[path];
@@ -445,6 +448,8 @@ shade_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps, uint32_t bounce, uint3
 // barrier is involved, so the waves of a workgroup never wait for one another.
 const uint32_t kWaveFlushAt = 128;
 const uint32_t kWaveStage = kWaveFlushAt + 64;
+const uint32_t kDeferFlushAt = 32;  // (deferred hits are few)
+const uint32_t kDeferStage = kDeferFlushAt + 64;
 
 RT_DEV void wave_flush(const uint32_t* stage, uint32_t n, uint32_t* g_counter, uint32_t* g_queue) {
   wave_lds_sync();
@@ -455,16 +460,27 @@ RT_DEV void wave_flush(const uint32_t* stage, uint32_t n, uint32_t* g_counter, u
   wave_lds_sync();
 }
 
+// MEDIA marks the general variant: constant media, records tied to the reference's box
+// chain, and deferral.  A hit on a material whose texture is not a SolidColor is not
+// shaded here (a Perlin walk needs twice the registers of everything else together, and
+// would set the occupancy of every ray): the ray, its t and the leaf slot are written out
+// and the path goes to the deferred queue, which shade_kernel<kAnyBin> works off after
+// this launch, appending its survivors to the same next-bounce queue.
 // TAIL: once few paths are left, a launch costs more than its rays (a wave needs tens of
 // microseconds for one bounce however empty the chip is).  The tail variant takes the queue
 // of bounce `bounce` and carries each wave's 64 paths through all remaining bounces in
 // place, dead lanes idle: one launch instead of one per bounce.
+#ifndef RT_TRACE_MEDIA_WAVES
+#define RT_TRACE_MEDIA_WAVES 3
+#endif
 template <int BLOCK, bool STATS, bool MEDIA, bool OVERFLOW, bool TAIL>
-__global__ void __launch_bounds__(BLOCK, 4)  // registers for four waves per SIMD
+__global__ void __launch_bounds__(BLOCK, MEDIA ? RT_TRACE_MEDIA_WAVES : 4)  // waves per SIMD to fit registers for
 trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_t first_bounce,
              uint32_t max_depth, unsigned long long* g_stats) {
   extern __shared__ __align__(16) char smem[];
   __shared__ uint32_t s_next[(BLOCK / 64) * kWaveStage];
+  constexpr bool DEFER = MEDIA && !TAIL;  // (the host runs no tail for scenes that defer)
+  __shared__ uint32_t s_defer[DEFER ? (BLOCK / 64) * kDeferStage : 1];
   const uint32_t* live = pb.live[first_bounce & 1u];
   uint32_t* next_live = pb.live[(first_bounce + 1u) & 1u];
   uint32_t* counters = pb.counters + (size_t)first_bounce * kCounterStride;
@@ -474,7 +490,8 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
   if (blockIdx.x * (uint32_t)BLOCK >= n_live) return;
   const LdsScene lds = lds_stage(sc, lay, smem, threadIdx.x, BLOCK);  // the only workgroup barrier
   uint32_t* stage = s_next + (threadIdx.x / 64u) * kWaveStage;
-  uint32_t n_staged = 0;  // wave-uniform
+  uint32_t* defer_stage = s_defer + (DEFER ? (threadIdx.x / 64u) * kDeferStage : 0u);
+  uint32_t n_staged = 0, n_deferred = 0;  // wave-uniform
   Stats st;
   if (STATS) st.clear();
   const uint32_t stride = gridDim.x * (uint32_t)BLOCK;
@@ -486,7 +503,7 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
     uint32_t path = 0;
     if (valid) path = first_bounce == 0 ? i : live[i];
     uint32_t bounce = first_bounce;
-    bool survives;
+    bool survives, deferred = false;
     do {
       survives = false;
       DrawKey key{ps.seed, 0u, 0u, bounce};
@@ -526,6 +543,13 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
           stat<STATS>(st, RT_STAT_SHADE_MISS);
           add = vmul(beta, v3(sc.bg));
           adds = true;
+        } else if (DEFER && (h.kind & kTexturedBit)) {
+          stat<STATS>(st, RT_STAT_HITS);
+          deferred = true;
+          pb.ray_o[path] = make_double4(o.x, o.y, o.z, time);
+          pb.ray_d[path] = make_double4(d.x, d.y, d.z, h.t);
+          pb.hit_item[path] = h.item;
+          if (bounce == 0) pb.beta[path] = make_double4(1.0, 1.0, 1.0, 0.0);
         } else {
           stat<STATS>(st, RT_STAT_HITS);
           RT_LP(st, LP_SHADE);
@@ -576,8 +600,21 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
         n_staged = 0;
       }
     }
+    if (DEFER) {
+      const unsigned long long mask = __ballot(deferred);
+      if (mask != 0ull) {
+        if (deferred)
+          defer_stage[n_deferred + (uint32_t)__popcll(mask & ((1ull << lane_id()) - 1ull))] = path;
+        n_deferred += (uint32_t)__popcll(mask);
+        if (n_deferred >= kDeferFlushAt) {
+          wave_flush(defer_stage, n_deferred, counters + kAnyBin, pb.bins);
+          n_deferred = 0;
+        }
+      }
+    }
   }
   if (!TAIL && n_staged) wave_flush(stage, n_staged, counters + 6, next_live);
+  if (DEFER && n_deferred) wave_flush(defer_stage, n_deferred, counters + kAnyBin, pb.bins);
   if (STATS) flush_stats(st, g_stats);
 }
 
@@ -723,6 +760,9 @@ struct rt_ctx {
   // path buffers, grown on demand
   PathBuffers pb{};
   uint64_t pb_capacity = 0;
+  uint32_t pb_queues = 0;  // bin queues allocated in pb.bins
+  bool solid = true;       // every texture is a SolidColor
+  bool general = false;    // the scene needs the general trace kernel
   uint32_t counters_depth = 0;
   DeviceArray<double> accum;
   DeviceArray<unsigned long long> stats;
@@ -771,12 +811,16 @@ void free_paths(rt_ctx* ctx) {
     if (p) (void)hipFree(p);
   pb = PathBuffers{};
   ctx->pb_capacity = 0;
+  ctx->pb_queues = 0;
   ctx->counters_depth = 0;
 }
 
-int ensure_paths(rt_ctx* ctx, uint64_t capacity, uint32_t max_depth, bool binned) {
+// `queues`: bin queues the pipeline needs (0: fused with nothing deferred, 1: the deferred
+// queue, kBins: binned); the hit slot array exists whenever a queue does.
+int ensure_paths(rt_ctx* ctx, uint64_t capacity, uint32_t max_depth, uint32_t queues) {
   PathBuffers& pb = ctx->pb;
-  if (capacity > ctx->pb_capacity || (binned && !pb.bins)) {
+  if (capacity > ctx->pb_capacity || queues > ctx->pb_queues) {
+    queues = std::max(queues, ctx->pb_queues);
     capacity = std::max(capacity, ctx->pb_capacity);
     uint32_t* keep_counters = pb.counters;
     uint32_t keep_depth = ctx->counters_depth;
@@ -790,12 +834,13 @@ int ensure_paths(rt_ctx* ctx, uint64_t capacity, uint32_t max_depth, bool binned
     RT_HIP(ctx, hipMalloc((void**)&pb.radiance, capacity * sizeof(double4)));
     RT_HIP(ctx, hipMalloc((void**)&pb.live[0], capacity * sizeof(uint32_t)));
     RT_HIP(ctx, hipMalloc((void**)&pb.live[1], capacity * sizeof(uint32_t)));
-    if (binned) {  // only the extend / shade pipeline records hits and bins paths
+    if (queues) {  // hits are recorded and paths queued only for a separate shade kernel
       RT_HIP(ctx, hipMalloc((void**)&pb.hit_item, capacity * sizeof(uint32_t)));
-      RT_HIP(ctx, hipMalloc((void**)&pb.bins, capacity * kBins * sizeof(uint32_t)));
+      RT_HIP(ctx, hipMalloc((void**)&pb.bins, capacity * queues * sizeof(uint32_t)));
     }
     pb.capacity = capacity;
     ctx->pb_capacity = capacity;
+    ctx->pb_queues = queues;
   }
   if (max_depth > ctx->counters_depth) {
     if (pb.counters) (void)hipFree(pb.counters);
@@ -1014,14 +1059,15 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats) {
   const uint32_t max_grid = ctx->n_cus * ctx->blocks_per_cu;
   // the MEDIA kernels carry the rare cases: constant media and records tied to the reference's box chain
   const bool media = ctx->flat.has_media || !ctx->flat.chain_ranges.empty();
-  bool solid = true;
-  for (const DTexture& t : ctx->flat.textures) solid = solid && t.kind == RT_TEX_SOLID;
-  // scenes whose shading is cheap run traversal and scatter fused; RT_FLAG_BINNED forces the
-  // extend / shade-per-material pipeline
-  const bool fused = solid && !(p->flags & RT_FLAG_BINNED);
+  const bool solid = ctx->solid;
+  // traversal and scatter run fused, with the hits on procedural or image textures deferred
+  // to a shade kernel of their own; RT_FLAG_BINNED forces the extend / shade-per-material pipeline
+  const bool fused = !(p->flags & RT_FLAG_BINNED);
+  const bool defer = fused && !solid;
+  const bool general = ctx->general;
   uint32_t bins_present = 1u;
   for (const DMaterial& m : ctx->flat.materials) bins_present |= 2u << m.kind;
-  rc = ensure_paths(ctx, n_pix * per_pass, p->max_depth, !fused);
+  rc = ensure_paths(ctx, n_pix * per_pass, p->max_depth, fused ? (defer ? 1u : 0u) : kBins);
   if (rc != RT_OK) return rc;
 
   for (uint32_t done = 0; done < n_samples; done += per_pass) {
@@ -1045,8 +1091,14 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats) {
       if (want_timing) RT_HIP(ctx, stamp());
       if (fused) {
         // cheap shading: traversal and scatter in one kernel per bounce
-        launch_trace(ctx, want_stats, media, false, tgrid, pb, ps, b, p->max_depth, gs);
+        launch_trace(ctx, want_stats, general, false, tgrid, pb, ps, b, p->max_depth, gs);
         if (want_timing) RT_HIP(ctx, stamp());
+        if (defer)
+          with_bool(want_stats, [&](auto S) {
+            shade_kernel<kAnyBin, decltype(S)::value, false>
+                <<<grid, kBlock, 0, ctx->stream>>>(ctx->ds, pb, ps, b, p->max_depth, gs);
+            return 0;
+          });
       } else {
         launch_extend(ctx, want_stats, media, grid, pb, ps, b, gs);
         if (want_timing) RT_HIP(ctx, stamp());
@@ -1070,10 +1122,10 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats) {
         if (live == 0) break;
         grid = std::max(1u, std::min(blocks_for(live), max_grid));
         tgrid = std::max(1u, trace_blocks_for(live));
-        if (fused && live <= ctx->tail_paths) {
+        if (fused && !defer && live <= ctx->tail_paths) {
           // few paths left: all remaining bounces in one launch
           if (want_timing) RT_HIP(ctx, stamp());
-          launch_trace(ctx, want_stats, media, true, tgrid, pb, ps, b + 1, p->max_depth, gs);
+          launch_trace(ctx, want_stats, general, true, tgrid, pb, ps, b + 1, p->max_depth, gs);
           if (want_timing) {
             RT_HIP(ctx, stamp());
             RT_HIP(ctx, stamp());
@@ -1227,21 +1279,28 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* scene) {
       l.bytes -= (l.n_prims - n) * kPrimHotBytes;
       l.n_prims = n;
     }
-    uint32_t tb = 512u;
+    // The general trace kernel (media, box chains, deferred textures) needs ~165 registers:
+    // 256-thread workgroups, three to a CU (3 waves per SIMD); the plain one fits 128 registers
+    // and runs 512-thread workgroups, two to a CU (4 waves per SIMD).
+    bool solid = true;
+    for (const DTexture& t : f.textures) solid = solid && t.kind == RT_TEX_SOLID;
+    ctx->solid = solid;
+    ctx->general = f.has_media || !f.chain_ranges.empty() || !solid;
+    uint32_t tb = ctx->general ? 256u : 512u;
     if (const char* e = getenv("MI355RT_TRACE_BLOCK")) tb = (uint32_t)strtoul(e, nullptr, 10);
     if (tb != 256u && tb != 512u)
       return fail(ctx, RT_ERR_INVALID, "MI355RT_TRACE_BLOCK must be 256 or 512");
     ctx->trace_block = tb;
-    // LDS of a CU split between the resident workgroups (4 waves per SIMD in all three cases),
-    // minus the per-wave queue stages
-    const uint32_t stage_bytes = (tb / 64u) * kWaveStage * 4u;
-    uint32_t tbudget = (160u * 1024u) / (1024u / tb) - stage_bytes - 1024u;
+    const uint32_t per_cu = ctx->general ? (tb == 256u ? 3u : 1u) : 1024u / tb;  // resident
+    ctx->trace_blocks_per_cu = 4096u / tb;  // launched: the grid drains more evenly in smaller pieces
+    if (const char* e = getenv("MI355RT_TRACE_BLOCKS_PER_CU"))
+      ctx->trace_blocks_per_cu = std::max(1u, (uint32_t)strtoul(e, nullptr, 10));
+    // LDS of a CU split between the resident workgroups, minus the per-wave queue stages
+    const uint32_t stage_bytes = (tb / 64u) * (kWaveStage + (ctx->general ? kDeferStage : 0u)) * 4u;
+    uint32_t tbudget = (160u * 1024u) / per_cu - stage_bytes - 1024u;
     if (const char* e = getenv("MI355RT_TRACE_LDS_BYTES")) tbudget = (uint32_t)strtoul(e, nullptr, 10);
     tbudget = std::min(tbudget, 160u * 1024u - stage_bytes - 512u);
     ctx->lds_trace = plan_lds(f, tb, tbudget, stack_cap);
-    ctx->trace_blocks_per_cu = 4096u / tb;
-    if (const char* e = getenv("MI355RT_TRACE_BLOCKS_PER_CU"))
-      ctx->trace_blocks_per_cu = std::max(1u, (uint32_t)strtoul(e, nullptr, 10));
     // overflow area for the stack entries LDS does not hold: one column per thread of the
     // largest grid any traversal kernel is launched with
     ctx->stack_overflow.release();

@@ -157,6 +157,50 @@ def test_stats_match_flat_oracle(gpu_ctx, golden_dir):
     assert st[abi.STAT_NAMES.index("node_visits")] == rs[abi.STAT_NAMES.index("node_visits")] > 0
 
 
+@pytest.mark.parametrize("name", ["book2", "perlin", "globe", "checker_mirror", "emissive", "medium_demo"])
+def test_deferred_texture_hits_give_the_binned_image(gpu_ctx, golden_dir, name):
+    """Default pipeline (fused, hits on procedural / image textures deferred to their own shade
+    kernel) against the binned one: same image bit for bit, same operation counts."""
+    from raytracer_amd import abi
+    scene, g = load(golden_dir, name)
+    w, h = scene.width, scene.height
+    gpu_ctx.upload(scene)
+    depth = scene.max_depth
+    a, sa = gpu_ctx.render(gpu_ctx.params(w, h, 0, 3, depth, seed=4), dtype=np.float64, stats=True)
+    b, sb = gpu_ctx.render(gpu_ctx.params(w, h, 0, 3, depth, seed=4, flags=abi.RT_FLAG_BINNED),
+                           dtype=np.float64, stats=True)
+    assert np.array_equal(a, b)
+    assert list(sa[:20]) == list(sb[:20])
+    # one sample at the last allowed bounce only: the depth budget ends deferred paths too
+    a1 = gpu_ctx.render(gpu_ctx.params(w, h, 0, 2, 1, seed=4), dtype=np.float64)
+    b1 = gpu_ctx.render(gpu_ctx.params(w, h, 0, 2, 1, seed=4, flags=abi.RT_FLAG_BINNED), dtype=np.float64)
+    assert np.array_equal(a1, b1)
+
+
+@pytest.mark.parametrize("block,per_cu", [("256", "1"), ("256", "4"), ("256", "16"), ("512", "1"), ("512", "2"),
+                                          ("512", "8")])
+def test_grid_shape_does_not_change_the_image(gpu_ctx, golden_dir, monkeypatch, block, per_cu):
+    """Workgroup size and grid size of the fused kernel only change which wave carries which path:
+    image and operation counts stay those of the binned pipeline (mixed scenes: some hits shaded
+    in place, some deferred, with and without media)."""
+    from raytracer_amd import abi
+    for name in ("checker_mirror", "book2", "book_cover"):
+        scene, g = load(golden_dir, name)
+        w, h = scene.width, scene.height
+        depth = scene.max_depth
+        gpu_ctx.upload(scene)
+        want, sw = gpu_ctx.render(gpu_ctx.params(w, h, 0, 3, depth, seed=4, flags=abi.RT_FLAG_BINNED),
+                                  dtype=np.float64, stats=True)
+        monkeypatch.setenv("MI355RT_TRACE_BLOCK", block)
+        monkeypatch.setenv("MI355RT_TRACE_BLOCKS_PER_CU", per_cu)
+        gpu_ctx.upload(scene)
+        got, sg = gpu_ctx.render(gpu_ctx.params(w, h, 0, 3, depth, seed=4), dtype=np.float64, stats=True)
+        monkeypatch.delenv("MI355RT_TRACE_BLOCK")
+        monkeypatch.delenv("MI355RT_TRACE_BLOCKS_PER_CU")
+        assert list(sw[:20]) == list(sg[:20]), name
+        assert np.array_equal(want, got), name
+
+
 @pytest.mark.parametrize("name", ["book_cover", "book2"])
 def test_stack_overflow_area_gives_the_same_image(gpu_ctx, golden_dir, name, monkeypatch):
     """With almost no LDS stack, nearly every stacked entry goes through the global overflow area."""
@@ -241,6 +285,11 @@ def test_random_scenes_match_the_oracle(gpu_ctx, first_seed, textured):
         assert np.array_equal(ids, rid) and np.array_equal(t, rt_) and np.array_equal(n, rn), f"seed {seed}"
         img = gpu_ctx.render(gpu_ctx.params(w, h, 0, 2, scene.max_depth, seed=5), dtype=np.float64)
         ref = o.render(po.make_params(w, h, 0, 2, scene.max_depth, 5), po.MODE_ITERATIVE, threads=4)
+        if textured:  # the pipelines agree exactly, libm or not
+            from raytracer_amd import abi
+            binned = gpu_ctx.render(gpu_ctx.params(w, h, 0, 2, scene.max_depth, seed=5, flags=abi.RT_FLAG_BINNED),
+                                    dtype=np.float64)
+            assert np.array_equal(img, binned), f"seed {seed}"
         if textured or "ConstantMedium" in text:
             close = np.isclose(img, ref, rtol=1e-9, atol=1e-12)
             assert close.mean() > 0.995, f"seed {seed}: {(~close).sum()} values differ"

@@ -41,6 +41,17 @@ for f in funcs:
         kind = ("valu" if op.startswith("v_") else "salu" if op.startswith("s_") else
                 "lds" if op.startswith("ds_") else "vmem")
         counts[cur][kind] += 1
+        if kind == "valu":
+            # issue cycles per wave64 as measured by tools/ubench/valu_rates.hip (rounded)
+            if re.match(r"v_(rcp|rsq|sqrt)_f64", op):
+                cyc = 18
+            elif "_f64" in op or op.startswith("v_pk_") or re.match(r"v_mul_(lo|hi)_[ui]32|v_mad_[ui]64", op):
+                cyc = 4
+            else:
+                cyc = 2
+            counts[cur]["cycles"] += cyc
+            if "_f64" in op:
+                counts[cur]["f64"] += 1
     print(name[:70])
     for k, c in counts.items():
-        print(f"  {k:12s} depth {depth.get(k, 0)}  valu {c['valu']:5d} salu {c['salu']:5d} lds {c['lds']:4d} vmem {c['vmem']:4d}")
+        print(f"  {k:12s} depth {depth.get(k, 0)}  valu {c['valu']:5d} salu {c['salu']:5d} lds {c['lds']:4d} vmem {c['vmem']:4d}  f64 {c['f64']:4d}  est. VALU cycles {c['cycles']:5d}")
