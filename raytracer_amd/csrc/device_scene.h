@@ -24,7 +24,8 @@ enum DPrimKind : uint32_t {
 //              (rt_material_kind) of `material`, bit 11 "texture needs (u,v)",
 //              bit 12 "a hit counts only if the ray passes the reference's box chain"
 //              (a cuboid side that sticks out of Cuboid::bounding_box, see FlatScene::chain_boxes),
-//              bit 13 "the material's texture is not a SolidColor" (its shading is the costly kind).
+//              bit 13 "shade hits on this record in the deferred kernel" (a texture that is not a
+//              SolidColor: see FlatScene::defers).
 //   ops word : first op (low 24 bits) | op count (high 8 bits), outermost first.
 //   sphere        p = {cx, cy, cz, radius, -}
 //   moving sphere p = {c0x, c0y, c0z, radius, time0}, p5 = aux index; aux = {c1x, c1y, c1z, time1}
@@ -82,7 +83,7 @@ const uint32_t kMaxBvhDepth = 32;      // levels of the binary tree the wide one
 const uint32_t kMaxLeafItems = 8;     // upper bound; the builder's default is lower
 const uint32_t kNoPrim = 0xFFFFFFFFu;
 const uint32_t kChainBit = 1u << 12;
-const uint32_t kTexturedBit = 1u << 13;
+const uint32_t kDeferBit = 1u << 13;
 
 // Everything the device needs, still in host memory.
 struct FlatScene {
@@ -112,6 +113,10 @@ struct FlatScene {
   uint32_t bvh_depth = 0;      // levels of the wide hierarchy
   uint32_t stack_entries = 1;  // traversal stack entries a ray can need
   bool has_media = false;
+  // The fused kernel shades a wave's hits in place, every material kind present in the wave
+  // one after the other.  Hits on materials with procedural or image textures are marked
+  // (kDeferBit) and shaded by a kernel of their own over a compacted queue.
+  bool defers = false;  // some record carries kDeferBit
 };
 
 // Flatten + build.  Returns "" on success, else an error message; `code`

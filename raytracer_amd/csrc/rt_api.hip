@@ -45,7 +45,14 @@ namespace {
 
 const int kBlock = 256;
 const uint32_t kBins = 1 + RT_MAT_KINDS;  // miss + one per material kind
-const uint32_t kCounterStride = 8;        // [0..5] bin sizes, [6] next live count, [7] deferred hits
+// The queue of live paths is kept as kSubQueues queues, each with its own counter in its own
+// 128-byte line; a workgroup appends to the one its index selects.  Returning atomics on one
+// line are served one after the other (about 90 per microsecond), and the fused kernel's waves
+// together come close to that rate; spread over eight lines they no longer wait for each other.
+// Counter row of one bounce (words): [0..5] bin sizes, [kAnyBin] deferred hits,
+// [32 * (1 + q)] entries of sub-queue q of the next bounce's live queue.
+const uint32_t kSubQueues = 8;
+const uint32_t kCounterStride = 32 * (1 + kSubQueues);
 const int kAnyBin = 7;                    // shade_kernel over the deferred queue: any material kind
 
 struct PathBuffers {
@@ -54,7 +61,7 @@ struct PathBuffers {
   double4* beta;      // running attenuation product
   double4* radiance;  // running radiance
   uint32_t* hit_item; // leaf slot hit, or kNoPrim
-  uint32_t* live[2];  // live-path queues, ping-pong
+  uint32_t* live[2];  // live-path queues, ping-pong; each kSubQueues regions of `capacity` entries
   uint32_t* bins;     // kBins queues of `capacity` entries (binned pipeline), or the one deferred queue
   uint32_t* counters; // (max_depth) x kCounterStride
   uint64_t capacity;
@@ -98,6 +105,45 @@ struct PassInfo {
 };
 
 RT_DEV uint32_t lane_id() { return __lane_id(); }
+
+// Where workgroup `block` appends the paths that live on after `bounce`.
+RT_DEV uint32_t* next_live_counter(const PathBuffers& pb, uint32_t bounce, uint32_t block) {
+  return pb.counters + (size_t)bounce * kCounterStride + 32u * (1u + (block % kSubQueues));
+}
+RT_DEV uint32_t* next_live_queue(const PathBuffers& pb, uint32_t bounce, uint32_t block) {
+  return pb.live[(bounce + 1u) & 1u] + (size_t)(block % kSubQueues) * pb.capacity;
+}
+// The live paths of `bounce` as one index range over the sub-queues the previous bounce
+// filled (bounce 0: every path of the pass, in order).
+struct LiveIn {
+  uint32_t start[kSubQueues + 1];  // start[q] = entries in the sub-queues before q
+  const uint32_t* queue;
+  uint64_t capacity;
+  uint32_t identity;
+  RT_DEV uint32_t total() const { return start[kSubQueues]; }
+  RT_DEV uint32_t path(uint32_t i) const {
+    if (identity) return i;
+    uint32_t q = 0;
+#pragma unroll
+    for (uint32_t k = 1; k < kSubQueues; ++k) q += i >= start[k] ? 1u : 0u;
+    uint32_t first = start[0];
+#pragma unroll
+    for (uint32_t k = 1; k < kSubQueues; ++k) first = q >= k ? start[k] : first;
+    return queue[(size_t)q * capacity + (i - first)];
+  }
+};
+RT_DEV LiveIn live_in(const PathBuffers& pb, uint32_t bounce, uint32_t n_paths) {
+  LiveIn li;
+  li.queue = pb.live[bounce & 1u];
+  li.capacity = pb.capacity;
+  li.identity = bounce == 0 ? 1u : 0u;
+  li.start[0] = 0;
+  const uint32_t* row = pb.counters + (size_t)(bounce == 0 ? 0u : bounce - 1u) * kCounterStride;
+#pragma unroll
+  for (uint32_t q = 0; q < kSubQueues; ++q)
+    li.start[q + 1] = bounce == 0 ? n_paths : li.start[q] + row[32u * (1u + q)];
+  return li;
+}
 
 // Queue appends are staged in LDS.  A returning atomic on one global word
 // saturates near 90 per microsecond on this chip, far below one per wave per
@@ -200,10 +246,9 @@ extend_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32
   __shared__ uint32_t s_bin[kBins * kStageCap];
   __shared__ uint32_t s_bin_count[kBins];
   __shared__ uint32_t s_word;
-  const uint32_t* live = pb.live[bounce & 1u];
+  const LiveIn live = live_in(pb, bounce, ps.n_paths);
   uint32_t* counters = pb.counters + (size_t)bounce * kCounterStride;
-  const uint32_t n_live =
-      bounce == 0 ? ps.n_paths : pb.counters[(size_t)(bounce - 1) * kCounterStride + 6];
+  const uint32_t n_live = live.total();
   Stats st;
   if (STATS) st.clear();
   const uint32_t stride = gridDim.x * kBlock;
@@ -216,7 +261,7 @@ extend_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32
     bool valid = i < n_live;
     uint32_t path = 0, bin = 0;
     if (valid) {
-      path = bounce == 0 ? i : live[i];
+      path = live.path(i);
       double4 ro = pb.ray_o[path];
       double4 rdv = pb.ray_d[path];
       uint32_t s_local = fastdiv(path, ps.by_pixels), local = path - s_local * ps.n_pixels;
@@ -359,7 +404,8 @@ shade_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps, uint32_t bounce, uint3
   constexpr bool kVector = BIN == 1 + RT_MAT_LAMBERTIAN || BIN == 1 + RT_MAT_METAL ||
                            BIN == 1 + RT_MAT_ISOTROPIC || BIN == kAnyBin;
   uint32_t* counters = pb.counters + (size_t)bounce * kCounterStride;
-  uint32_t* next_live = pb.live[(bounce + 1u) & 1u];
+  uint32_t* next_live = next_live_queue(pb, bounce, blockIdx.x);
+  uint32_t* next_count = next_live_counter(pb, bounce, blockIdx.x);
   const uint32_t total = counters[BIN];
   if (blockIdx.x * kBlock >= total) return;
   const uint32_t* queue = pb.bins + (BIN == kAnyBin ? (size_t)0 : (size_t)BIN * pb.capacity);
@@ -424,12 +470,12 @@ shade_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps, uint32_t bounce, uint3
       if (survives) s_next[slot] = path;
       __syncthreads();
       uint32_t n = s_next_count;
-      if (n >= kFlushAt) stage_flush(s_next, &s_next_count, &s_word, counters + 6, next_live, n);
+      if (n >= kFlushAt) stage_flush(s_next, &s_next_count, &s_word, next_count, next_live, n);
     }
   }
   if (BIN != 0 && BIN != 1 + RT_MAT_DIFFUSE_LIGHT) {
     uint32_t n = s_next_count;
-    if (n) stage_flush(s_next, &s_next_count, &s_word, counters + 6, next_live, n);
+    if (n) stage_flush(s_next, &s_next_count, &s_word, next_count, next_live, n);
   }
   if (STATS) flush_stats(st, g_stats);
 }
@@ -446,9 +492,15 @@ shade_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps, uint32_t bounce, uint3
 // out slots with ballot + prefix count, and moves the entries to the global
 // queue when kWaveFlushAt have gathered, with one global atomic.  No workgroup
 // barrier is involved, so the waves of a workgroup never wait for one another.
-const uint32_t kWaveFlushAt = 128;
+#ifndef RT_WAVE_FLUSH_AT
+#define RT_WAVE_FLUSH_AT 128
+#endif
+const uint32_t kWaveFlushAt = RT_WAVE_FLUSH_AT;
 const uint32_t kWaveStage = kWaveFlushAt + 64;
-const uint32_t kDeferFlushAt = 32;  // (deferred hits are few)
+#ifndef RT_DEFER_FLUSH_AT
+#define RT_DEFER_FLUSH_AT 32
+#endif
+const uint32_t kDeferFlushAt = RT_DEFER_FLUSH_AT;  // (deferred hits are few)
 const uint32_t kDeferStage = kDeferFlushAt + 64;
 
 RT_DEV void wave_flush(const uint32_t* stage, uint32_t n, uint32_t* g_counter, uint32_t* g_queue) {
@@ -460,12 +512,13 @@ RT_DEV void wave_flush(const uint32_t* stage, uint32_t n, uint32_t* g_counter, u
   wave_lds_sync();
 }
 
-// MEDIA marks the general variant: constant media, records tied to the reference's box
-// chain, and deferral.  A hit on a material whose texture is not a SolidColor is not
-// shaded here (a Perlin walk needs twice the registers of everything else together, and
-// would set the occupancy of every ray): the ray, its t and the leaf slot are written out
-// and the path goes to the deferred queue, which shade_kernel<kAnyBin> works off after
-// this launch, appending its survivors to the same next-bounce queue.
+// MEDIA marks the general variant: constant media and records tied to the reference's box
+// chain.  A hit on a record with kDeferBit is not shaded here: a Perlin walk needs twice the
+// registers of everything else together and would set the occupancy of every ray, and a
+// material kind that few lanes of a wave hit would still cost the whole wave its (long)
+// scatter code.  The ray, its t and the leaf slot are written out and the path goes to the
+// deferred queue, which shade_kernel<kAnyBin> works off after this launch at full lane
+// use, appending its survivors to the same next-bounce queue.
 // TAIL: once few paths are left, a launch costs more than its rays (a wave needs tens of
 // microseconds for one bounce however empty the chip is).  The tail variant takes the queue
 // of bounce `bounce` and carries each wave's 64 paths through all remaining bounces in
@@ -479,14 +532,13 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
              uint32_t max_depth, unsigned long long* g_stats) {
   extern __shared__ __align__(16) char smem[];
   __shared__ uint32_t s_next[(BLOCK / 64) * kWaveStage];
-  constexpr bool DEFER = MEDIA && !TAIL;  // (the host runs no tail for scenes that defer)
+  constexpr bool DEFER = !TAIL;  // (the tail shades everything in place; the host runs none for textured scenes)
   __shared__ uint32_t s_defer[DEFER ? (BLOCK / 64) * kDeferStage : 1];
-  const uint32_t* live = pb.live[first_bounce & 1u];
-  uint32_t* next_live = pb.live[(first_bounce + 1u) & 1u];
+  const LiveIn live = live_in(pb, first_bounce, ps.n_paths);
+  uint32_t* next_live = next_live_queue(pb, first_bounce, blockIdx.x);
+  uint32_t* next_count = next_live_counter(pb, first_bounce, blockIdx.x);
   uint32_t* counters = pb.counters + (size_t)first_bounce * kCounterStride;
-  const uint32_t n_live = first_bounce == 0
-                              ? ps.n_paths
-                              : pb.counters[(size_t)(first_bounce - 1) * kCounterStride + 6];
+  const uint32_t n_live = live.total();
   if (blockIdx.x * (uint32_t)BLOCK >= n_live) return;
   const LdsScene lds = lds_stage(sc, lay, smem, threadIdx.x, BLOCK);  // the only workgroup barrier
   uint32_t* stage = s_next + (threadIdx.x / 64u) * kWaveStage;
@@ -501,10 +553,13 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
     const uint32_t i = base + (threadIdx.x & 63u);
     bool valid = i < n_live;
     uint32_t path = 0;
-    if (valid) path = first_bounce == 0 ? i : live[i];
+    if (valid) path = live.path(i);
     uint32_t bounce = first_bounce;
     bool survives, deferred = false;
     do {
+#ifdef RT_LANE_PROFILE
+      unsigned long long tick = __builtin_readcyclecounter();
+#endif
       survives = false;
       DrawKey key{ps.seed, 0u, 0u, bounce};
       ShadeOut so;
@@ -529,7 +584,9 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
         }
         stat<STATS>(st, RT_STAT_RAYS);
         RT_LP(st, LP_RAY);
+        RT_TICK(st, LP_T_SETUP, tick);
         Closest h = closest_hit<STATS, MEDIA, MEDIA, OVERFLOW>(sc, lds, o, d, time, 0.001, key, st);
+        RT_TICK(st, LP_T_TRAVERSE, tick);
         // ... and starts from beta = 1, L = 0
         V3 beta = v3(1.0, 1.0, 1.0);
         if (bounce != 0) {
@@ -543,7 +600,7 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
           stat<STATS>(st, RT_STAT_SHADE_MISS);
           add = vmul(beta, v3(sc.bg));
           adds = true;
-        } else if (DEFER && (h.kind & kTexturedBit)) {
+        } else if (DEFER && (h.kind & kDeferBit)) {
           stat<STATS>(st, RT_STAT_HITS);
           deferred = true;
           pb.ray_o[path] = make_double4(o.x, o.y, o.z, time);
@@ -576,14 +633,17 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
           pb.radiance[path] = make_double4(L.x + add.x, L.y + add.y, L.z + add.z, 0.0);
         }
       }
+      RT_TICK(st, LP_T_SHADE, tick);
       {  // whole waves: the lanes look for their random vectors together
         // (the wave's part of the first two stack rows is idle between traversals)
         V3 inside = wave_rand_in_unit_sphere(survives && so.needs_vector, key,
                                              lds.stack - (threadIdx.x & 63u), BLOCK, st);
+        RT_TICK(st, LP_T_VECTOR, tick);
         shade_finish(so, inside);
       }
       if (survives)
         pb.ray_d[path] = make_double4(so.direction.x, so.direction.y, so.direction.z, 0.0);
+      RT_TICK(st, LP_T_STORE, tick);
       if (TAIL) {
         // the same lane reads its own stores back: program order, no fence needed
         valid = survives;
@@ -596,7 +656,7 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
         stage[n_staged + (uint32_t)__popcll(mask & ((1ull << lane_id()) - 1ull))] = path;
       n_staged += (uint32_t)__popcll(mask);
       if (n_staged >= kWaveFlushAt) {
-        wave_flush(stage, n_staged, counters + 6, next_live);
+        wave_flush(stage, n_staged, next_count, next_live);
         n_staged = 0;
       }
     }
@@ -613,7 +673,7 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
       }
     }
   }
-  if (!TAIL && n_staged) wave_flush(stage, n_staged, counters + 6, next_live);
+  if (!TAIL && n_staged) wave_flush(stage, n_staged, next_count, next_live);
   if (DEFER && n_deferred) wave_flush(defer_stage, n_deferred, counters + kAnyBin, pb.bins);
   if (STATS) flush_stats(st, g_stats);
 }
@@ -832,8 +892,8 @@ int ensure_paths(rt_ctx* ctx, uint64_t capacity, uint32_t max_depth, uint32_t qu
     RT_HIP(ctx, hipMalloc((void**)&pb.ray_d, capacity * sizeof(double4)));
     RT_HIP(ctx, hipMalloc((void**)&pb.beta, capacity * sizeof(double4)));
     RT_HIP(ctx, hipMalloc((void**)&pb.radiance, capacity * sizeof(double4)));
-    RT_HIP(ctx, hipMalloc((void**)&pb.live[0], capacity * sizeof(uint32_t)));
-    RT_HIP(ctx, hipMalloc((void**)&pb.live[1], capacity * sizeof(uint32_t)));
+    RT_HIP(ctx, hipMalloc((void**)&pb.live[0], capacity * kSubQueues * sizeof(uint32_t)));
+    RT_HIP(ctx, hipMalloc((void**)&pb.live[1], capacity * kSubQueues * sizeof(uint32_t)));
     if (queues) {  // hits are recorded and paths queued only for a separate shade kernel
       RT_HIP(ctx, hipMalloc((void**)&pb.hit_item, capacity * sizeof(uint32_t)));
       RT_HIP(ctx, hipMalloc((void**)&pb.bins, capacity * queues * sizeof(uint32_t)));
@@ -1063,7 +1123,7 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats) {
   // traversal and scatter run fused, with the hits on procedural or image textures deferred
   // to a shade kernel of their own; RT_FLAG_BINNED forces the extend / shade-per-material pipeline
   const bool fused = !(p->flags & RT_FLAG_BINNED);
-  const bool defer = fused && !solid;
+  const bool defer = fused && ctx->flat.defers;
   const bool general = ctx->general;
   uint32_t bins_present = 1u;
   for (const DMaterial& m : ctx->flat.materials) bins_present |= 2u << m.kind;
@@ -1095,9 +1155,11 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats) {
         if (want_timing) RT_HIP(ctx, stamp());
         if (defer)
           with_bool(want_stats, [&](auto S) {
-            shade_kernel<kAnyBin, decltype(S)::value, false>
-                <<<grid, kBlock, 0, ctx->stream>>>(ctx->ds, pb, ps, b, p->max_depth, gs);
-            return 0;
+            return with_bool(solid, [&](auto T) {
+              shade_kernel<kAnyBin, decltype(S)::value, decltype(T)::value>
+                  <<<grid, kBlock, 0, ctx->stream>>>(ctx->ds, pb, ps, b, p->max_depth, gs);
+              return 0;
+            });
           });
       } else {
         launch_extend(ctx, want_stats, media, grid, pb, ps, b, gs);
@@ -1114,15 +1176,16 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats) {
       // every 8 bounces look at the live count: stop when no path is left and
       // shrink the grid as the queues drain
       if ((b & 7u) == 7u && b + 1 < p->max_depth) {
-        RT_HIP(ctx, hipMemcpyAsync(ctx->h_probe, pb.counters + (size_t)b * kCounterStride + 6,
-                                   sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        RT_HIP(ctx, hipMemcpyAsync(ctx->h_probe, pb.counters + (size_t)b * kCounterStride,
+                                   kCounterStride * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        uint32_t live = *ctx->h_probe;
+        uint32_t live = 0;
+        for (uint32_t q = 0; q < kSubQueues; ++q) live += ctx->h_probe[32u * (1u + q)];
         if (want_timing) RT_HIP(ctx, drain());
         if (live == 0) break;
         grid = std::max(1u, std::min(blocks_for(live), max_grid));
         tgrid = std::max(1u, trace_blocks_for(live));
-        if (fused && !defer && live <= ctx->tail_paths) {
+        if (fused && solid && live <= ctx->tail_paths) {
           // few paths left: all remaining bounces in one launch
           if (want_timing) RT_HIP(ctx, stamp());
           launch_trace(ctx, want_stats, general, true, tgrid, pb, ps, b + 1, p->max_depth, gs);
@@ -1174,7 +1237,7 @@ int rt_create(const rt_config* cfg, rt_ctx** out) {
       hipGetDeviceProperties(&prop, ctx->device) != hipSuccess ||
       hipStreamCreate(&ctx->stream) != hipSuccess ||
       hipMalloc((void**)&ctx->stats.p, RT_STAT_COUNT * sizeof(unsigned long long)) != hipSuccess ||
-      hipHostMalloc((void**)&ctx->h_probe, 64) != hipSuccess) {
+      hipHostMalloc((void**)&ctx->h_probe, kCounterStride * sizeof(uint32_t)) != hipSuccess) {
     delete ctx;
     return RT_ERR_DEVICE;
   }
@@ -1184,11 +1247,11 @@ int rt_create(const rt_config* cfg, rt_ctx** out) {
   } else if (const char* e = getenv("MI355RT_MAX_PATHS")) {
     ctx->max_paths = std::max<uint64_t>(strtoull(e, nullptr, 10), 1u << 16);
   } else {
-    // default: a quarter of the free device memory at ~160 bytes of state per path,
+    // default: a quarter of the free device memory at ~224 bytes of state and queues per path,
     // between 2^22 and 2^27 paths (fewer, larger passes spend less time in their tails)
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
-    uint64_t fit = (uint64_t)(free_b / 4) / 160u;
+    uint64_t fit = (uint64_t)(free_b / 4) / 224u;
     ctx->max_paths = std::min<uint64_t>(std::max<uint64_t>(fit, 1ull << 22), 1ull << 27);
   }
   *out = ctx;
@@ -1279,13 +1342,13 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* scene) {
       l.bytes -= (l.n_prims - n) * kPrimHotBytes;
       l.n_prims = n;
     }
-    // The general trace kernel (media, box chains, deferred textures) needs ~165 registers:
+    // The general trace kernel (media, box chains) needs ~165 registers:
     // 256-thread workgroups, three to a CU (3 waves per SIMD); the plain one fits 128 registers
     // and runs 512-thread workgroups, two to a CU (4 waves per SIMD).
     bool solid = true;
     for (const DTexture& t : f.textures) solid = solid && t.kind == RT_TEX_SOLID;
     ctx->solid = solid;
-    ctx->general = f.has_media || !f.chain_ranges.empty() || !solid;
+    ctx->general = f.has_media || !f.chain_ranges.empty();
     uint32_t tb = ctx->general ? 256u : 512u;
     if (const char* e = getenv("MI355RT_TRACE_BLOCK")) tb = (uint32_t)strtoul(e, nullptr, 10);
     if (tb != 256u && tb != 512u)
@@ -1296,7 +1359,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* scene) {
     if (const char* e = getenv("MI355RT_TRACE_BLOCKS_PER_CU"))
       ctx->trace_blocks_per_cu = std::max(1u, (uint32_t)strtoul(e, nullptr, 10));
     // LDS of a CU split between the resident workgroups, minus the per-wave queue stages
-    const uint32_t stage_bytes = (tb / 64u) * (kWaveStage + (ctx->general ? kDeferStage : 0u)) * 4u;
+    const uint32_t stage_bytes = (tb / 64u) * (kWaveStage + kDeferStage) * 4u;
     uint32_t tbudget = (160u * 1024u) / per_cu - stage_bytes - 1024u;
     if (const char* e = getenv("MI355RT_TRACE_LDS_BYTES")) tbudget = (uint32_t)strtoul(e, nullptr, 10);
     tbudget = std::min(tbudget, 160u * 1024u - stage_bytes - 512u);

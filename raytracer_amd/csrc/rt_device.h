@@ -101,7 +101,9 @@ RT_DEV V3 rand_in_unit_disk(const DrawKey& k) {  // vec3.rs:49-60
 #ifdef RT_LANE_PROFILE
 // Development build only: per loop, how many wave-level trips ran and how many
 // lanes were active in them (trips[2k] = lane trips, trips[2k+1] = wave trips).
-enum { LP_RAY = 0, LP_OUTER, LP_NODE, LP_LEAFPRIM, LP_POP, LP_SHADE, LP_REJECT, LP_ROOTS, LP_COUNT };
+// LP_T_*: phases of one trip of trace_kernel; there trips[2k] = clock ticks summed over waves.
+enum { LP_RAY = 0, LP_OUTER, LP_NODE, LP_LEAFPRIM, LP_POP, LP_SHADE, LP_REJECT, LP_ROOTS,
+       LP_T_SETUP, LP_T_TRAVERSE, LP_T_SHADE, LP_T_VECTOR, LP_T_STORE, LP_COUNT };
 #endif
 struct Stats {
   uint32_t v[RT_STAT_COUNT];
@@ -123,9 +125,20 @@ RT_DEV void lane_trip(Stats& st, int loop) {
   st.trips[2 * loop]++;
   if ((int)__lane_id() == __ffsll((long long)m) - 1) st.trips[2 * loop + 1]++;
 }
+RT_DEV void lane_tick(Stats& st, int phase, unsigned long long& t0) {
+  unsigned long long t1 = __builtin_readcyclecounter();
+  unsigned long long m = __ballot(1);
+  if ((int)__lane_id() == __ffsll((long long)m) - 1) {
+    st.trips[2 * phase] += (uint32_t)(t1 - t0);
+    st.trips[2 * phase + 1]++;
+  }
+  t0 = t1;
+}
 #define RT_LP(st, loop) lane_trip(st, loop)
+#define RT_TICK(st, phase, t0) lane_tick(st, phase, t0)
 #else
 #define RT_LP(st, loop) ((void)0)
+#define RT_TICK(st, phase, t0) ((void)0)
 #endif
 template <bool ON>
 RT_DEV void stat(Stats& s, int which) {
