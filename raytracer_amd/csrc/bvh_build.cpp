@@ -518,6 +518,9 @@ uint32_t collapse_wide(const std::vector<BinNode>& bin, std::vector<rt_bvh_node>
   return std::max(1u, need[0]);
 }
 
+uint32_t pack_material(uint32_t material) {
+  return material < (1u << (32u - kMaterialShift)) ? material << kMaterialShift : kMaterialElsewhereBit;
+}
 uint32_t pack_ops(uint32_t first, uint32_t count) { return (first & 0x00FFFFFFu) | (count << 24); }
 
 }  // namespace
@@ -563,6 +566,7 @@ std::string flatten_scene(const rt_scene& s, FlatScene& out, int& code) {
                     m.kind == RT_MAT_ISOTROPIC;
     d.needs_uv = textured ? tex_needs_uv[m.texture] : 0;
     d.textured = textured && s.textures[m.texture].kind != RT_TEX_SOLID ? 1u : 0u;
+    if (textured && !d.textured) std::memcpy(d.albedo, s.textures[m.texture].color, sizeof d.albedo);
     out.materials[i] = d;
   }
   out.perlin.assign(s.perlin, s.perlin + s.n_perlin);
@@ -663,6 +667,7 @@ std::string flatten_scene(const rt_scene& s, FlatScene& out, int& code) {
       d.kind |= kDeferBit;
       out.defers = true;
     }
+    d.kind |= pack_material(p.material);
     return d;
   };
 
@@ -686,6 +691,7 @@ std::string flatten_scene(const rt_scene& s, FlatScene& out, int& code) {
         d.kind |= kDeferBit;
         out.defers = true;
       }
+      d.kind |= pack_material(o.medium_material);
       d.ops = pack_ops(o.first_op, o.op_count);
       d.material = o.medium_material;
       d.object = oi;

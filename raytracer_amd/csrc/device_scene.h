@@ -25,7 +25,9 @@ enum DPrimKind : uint32_t {
 //              bit 12 "a hit counts only if the ray passes the reference's box chain"
 //              (a cuboid side that sticks out of Cuboid::bounding_box, see FlatScene::chain_boxes),
 //              bit 13 "shade hits on this record in the deferred kernel" (a texture that is not a
-//              SolidColor: see FlatScene::defers).
+//              SolidColor: see FlatScene::defers), bits 15-31 the material index when it fits
+//              (bit 14 set: it does not, read `material`): what a hit is shaded with is then
+//              known from the 48 bytes the traversal has read anyway.
 //   ops word : first op (low 24 bits) | op count (high 8 bits), outermost first.
 //   sphere        p = {cx, cy, cz, radius, -}
 //   moving sphere p = {c0x, c0y, c0z, radius, time0}, p5 = aux index; aux = {c1x, c1y, c1z, time1}
@@ -58,7 +60,7 @@ struct DAux {  // 32 bytes
 struct DMaterial {  // 48 bytes
   uint32_t kind;
   uint32_t texture;
-  double albedo[3];
+  double albedo[3];  // textured kinds: the colour of `texture` when that is a SolidColor
   double param;
   uint32_t needs_uv;
   uint32_t textured;  // reads a texture that is not a SolidColor
@@ -84,6 +86,8 @@ const uint32_t kMaxLeafItems = 8;     // upper bound; the builder's default is l
 const uint32_t kNoPrim = 0xFFFFFFFFu;
 const uint32_t kChainBit = 1u << 12;
 const uint32_t kDeferBit = 1u << 13;
+const uint32_t kMaterialElsewhereBit = 1u << 14;
+const uint32_t kMaterialShift = 15;
 
 // Everything the device needs, still in host memory.
 struct FlatScene {

@@ -315,9 +315,16 @@ struct ShadeOut {
 
 // First half: everything up to the material's random unit vector.  For Lambertian,
 // Metal and Isotropic hits `direction` holds what the vector is added to.
+// Material index of a record (`pr` must have been loaded whole when the kind word does not hold it).
+RT_DEV uint32_t material_of(const DPrim& pr) {
+  return (pr.kind & kMaterialElsewhereBit) ? pr.material : pr.kind >> kMaterialShift;
+}
+
+// SOLID: the material's texture (if it has one) is known to be a SolidColor, whose colour the
+// material record carries: no texture walk, no (u, v).
 template <bool STATS, bool SOLID>
-RT_DEV ShadeOut shade_begin(const DeviceScene& sc, uint32_t kind, const DPrim& pr, V3 o, V3 d,
-                            double time, double t, const DrawKey& key, Stats& st) {
+RT_DEV ShadeOut shade_begin(const DeviceScene& sc, uint32_t kind, const DPrim& pr, uint32_t material,
+                            V3 o, V3 d, double time, double t, const DrawKey& key, Stats& st) {
   ShadeOut out;
   out.attenuation = v3(0.0, 0.0, 0.0);
   out.direction = v3(0.0, 0.0, 0.0);
@@ -328,7 +335,7 @@ RT_DEV ShadeOut shade_begin(const DeviceScene& sc, uint32_t kind, const DPrim& p
   out.emits = false;
   out.needs_vector = false;
   stat<STATS>(st, RT_STAT_SHADE_LAMBERTIAN + (int)kind);
-  const DMaterial m = sc.materials[pr.material];
+  const DMaterial m = sc.materials[material];
   const bool textured = kind == RT_MAT_LAMBERTIAN || kind == RT_MAT_DIFFUSE_LIGHT ||
                         kind == RT_MAT_ISOTROPIC;
   bool want_uv = textured && ((pr.kind >> 11) & 1u);
@@ -336,7 +343,7 @@ RT_DEV ShadeOut shade_begin(const DeviceScene& sc, uint32_t kind, const DPrim& p
   out.p = rec.p;
   if (kind == RT_MAT_LAMBERTIAN) {  // lambertian.rs:13-25
     out.direction = rec.normal;
-    out.attenuation = texture_value<STATS, SOLID>(sc, m.texture, rec.u, rec.v, rec.p, st);
+    out.attenuation = SOLID ? v3(m.albedo) : texture_value<STATS>(sc, m.texture, rec.u, rec.v, rec.p, st);
     out.scattered = true;
     out.needs_vector = true;
   } else if (kind == RT_MAT_METAL) {  // metal.rs:12-28
@@ -361,10 +368,10 @@ RT_DEV ShadeOut shade_begin(const DeviceScene& sc, uint32_t kind, const DPrim& p
     out.attenuation = v3(1.0, 1.0, 1.0);
     out.scattered = true;
   } else if (kind == RT_MAT_DIFFUSE_LIGHT) {  // emissive.rs:10-12; never scatters
-    out.emitted = texture_value<STATS, SOLID>(sc, m.texture, rec.u, rec.v, rec.p, st);
+    out.emitted = SOLID ? v3(m.albedo) : texture_value<STATS>(sc, m.texture, rec.u, rec.v, rec.p, st);
     out.emits = true;
   } else {  // isotropic.rs:10-17
-    out.attenuation = texture_value<STATS, SOLID>(sc, m.texture, rec.u, rec.v, rec.p, st);
+    out.attenuation = SOLID ? v3(m.albedo) : texture_value<STATS>(sc, m.texture, rec.u, rec.v, rec.p, st);
     out.scattered = true;
     out.needs_vector = true;
   }
@@ -442,7 +449,7 @@ shade_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps, uint32_t bounce, uint3
         key.pixel = y * ps.width + x;
         key.sample = ps.sample_base + s_local;
         const uint32_t kind = BIN == kAnyBin ? (pr.kind >> 8) & 7u : (uint32_t)BIN - 1u;
-        so = shade_begin<STATS, SOLID>(sc, kind, pr, v3(ro.x, ro.y, ro.z),
+        so = shade_begin<STATS, SOLID>(sc, kind, pr, material_of(pr), v3(ro.x, ro.y, ro.z),
                                        v3(rdv.x, rdv.y, rdv.z), ro.w, rdv.w, key, st);
         if (so.emits) {
           double4 L = pb.radiance[path];
@@ -610,8 +617,10 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
         } else {
           stat<STATS>(st, RT_STAT_HITS);
           RT_LP(st, LP_SHADE);
-          const DPrim pr = load_prim<true>(sc, lds, h.item);
-          so = shade_begin<STATS, true>(sc, (h.kind >> 8) & 7u, pr, o, d, time, h.t, key, st);
+          // (the cold quarter of the record only where something reads it)
+          const bool whole = (h.kind & kMaterialElsewhereBit) != 0u;
+          const DPrim pr = whole ? load_prim<true>(sc, lds, h.item) : load_prim<false>(sc, lds, h.item);
+          so = shade_begin<STATS, true>(sc, (h.kind >> 8) & 7u, pr, material_of(pr), o, d, time, h.t, key, st);
           if (so.emits) {
             add = vmul(beta, so.emitted);
             adds = true;

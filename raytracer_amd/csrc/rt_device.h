@@ -848,10 +848,9 @@ RT_DEV uint32_t as_u32_sat(double x) {
   return (uint32_t)x;
 }
 
-template <bool STATS, bool SOLID_ONLY = false>
+template <bool STATS>
 RT_DEV V3 texture_value(const DeviceScene& sc, uint32_t tex, double u, double v, V3 p, Stats& st) {
   DTexture t = sc.textures[tex];
-  if (SOLID_ONLY) return v3(t.color);  // every texture of the scene is a SolidColor
   // Checkerboard::value (checkerboard.rs:17-28); children have lower indices, so this ends
   while (t.kind == RT_TEX_CHECKER) {
     stat<STATS>(st, RT_STAT_TEX_CHECKER);
