@@ -39,8 +39,10 @@ RT_HD u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1) {
 #define RT_PHILOX_ROUNDS 10
 #endif
   for (int r = 0; r < RT_PHILOX_ROUNDS; ++r) {
-    uint32_t hi0 = mulhi32(M0, c.x), lo0 = M0 * c.x;
-    uint32_t hi1 = mulhi32(M1, c.z), lo1 = M1 * c.z;
+    // one 32x32->64 product each (v_mad_u64_u32 issues faster than v_mul_hi_u32 + v_mul_lo_u32)
+    const uint64_t p0 = (uint64_t)M0 * (uint64_t)c.x, p1 = (uint64_t)M1 * (uint64_t)c.z;
+    uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
     u32x4 n;
     n.x = hi1 ^ c.y ^ k0;
     n.y = lo1;

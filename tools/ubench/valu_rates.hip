@@ -14,6 +14,8 @@ __global__ void rate_kernel(unsigned long long* out, int iters) {
   unsigned u0 = threadIdx.x, u1 = u0 * 3 + 1, u2 = u0 * 5 + 2, u3 = u0 * 7 + 3;
   typedef float f2 __attribute__((ext_vector_type(2)));
   f2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7};
+  unsigned long long q0 = u0, q1 = u1, q2 = u2, q3 = u3;
+  unsigned um = 0xFFFF0000u ^ threadIdx.x;
   unsigned long long t0 = __builtin_readcyclecounter();
   for (int i = 0; i < iters; ++i) {
     if (KIND == 0) {
@@ -42,12 +44,26 @@ __global__ void rate_kernel(unsigned long long* out, int iters) {
       REP16(asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %1, %1, %2, vcc\n v_cndmask_b32 %2, %2, %3, vcc\n v_cndmask_b32 %3, %3, %0, vcc" : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : : "vcc");)
     } else if (KIND == 12) {
       REP16(asm volatile("v_rsq_f64 %0, %0\n v_rsq_f64 %1, %1\n v_rsq_f64 %2, %2\n v_rsq_f64 %3, %3" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));)
+    } else if (KIND == 14) {  // 32x32 -> 64-bit product (+ 64-bit addend) in one instruction
+      REP16(asm volatile("v_mad_u64_u32 %0, vcc, %4, %5, %0\n v_mad_u64_u32 %1, vcc, %5, %6, %1\n v_mad_u64_u32 %2, vcc, %6, %7, %2\n v_mad_u64_u32 %3, vcc, %7, %4, %3" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) : "v"(u0), "v"(u1), "v"(u2), "v"(u3) : "vcc");)
+    } else if (KIND == 15) {
+      REP16(asm volatile("v_min3_f32 %0, %0, %1, %2\n v_max3_f32 %1, %1, %2, %3\n v_min3_f32 %2, %2, %3, %0\n v_max3_f32 %3, %3, %0, %1" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));)
+    } else if (KIND == 16) {
+      REP16(asm volatile("v_sqrt_f64 %0, %0\n v_sqrt_f64 %1, %1\n v_sqrt_f64 %2, %2\n v_sqrt_f64 %3, %3" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));)
+    } else if (KIND == 17) {
+      REP16(asm volatile("v_lshl_add_u32 %0, %0, 1, %1\n v_lshl_or_b32 %1, %1, 2, %2\n v_add3_u32 %2, %2, %3, %0\n v_bfe_u32 %3, %3, 1, 9" : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3));)
+    } else if (KIND == 18) {  // select by an SGPR pair that is not VCC
+      REP16(asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[10:11]\n v_cndmask_b32_e64 %1, %1, %2, s[10:11]\n v_cndmask_b32_e64 %2, %2, %3, s[10:11]\n v_cndmask_b32_e64 %3, %3, %0, s[10:11]" : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : : "s10", "s11");)
+    } else if (KIND == 19) {  // select by a mask held in a vector register
+      REP16(asm volatile("v_bfi_b32 %0, %4, %0, %1\n v_bfi_b32 %1, %4, %1, %2\n v_bfi_b32 %2, %4, %2, %3\n v_bfi_b32 %3, %4, %3, %0" : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(um));)
+    } else if (KIND == 20) {  // compare into VCC, then select by it
+      REP16(asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cndmask_b32 %2, %2, %3, vcc\n v_cmp_lt_f32 vcc, %1, %0\n v_cndmask_b32 %3, %3, %2, vcc" : "+v"(a0), "+v"(a1), "+v"(u2), "+v"(u3) : : "vcc");)
     } else if (KIND == 13) {
       REP16(asm volatile("v_cvt_f64_u32 %0, %4\n v_cvt_f64_u32 %1, %5\n v_cvt_f64_u32 %2, %6\n v_cvt_f64_u32 %3, %7" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(u0), "v"(u1), "v"(u2), "v"(u3));)
     }
   }
   unsigned long long t1 = __builtin_readcyclecounter();
-  float sink = a0 + a1 + a2 + a3 + p0.x + p1.y + p2.x + p3.y + (float)(d0 + d1 + d2 + d3) + (float)(u0 ^ u1 ^ u2 ^ u3);
+  float sink = a0 + a1 + a2 + a3 + p0.x + p1.y + p2.x + p3.y + (float)(d0 + d1 + d2 + d3) + (float)(u0 ^ u1 ^ u2 ^ u3) + (float)(q0 ^ q1 ^ q2 ^ q3);
   if (sink == 12345.678f) out[1] = 1;
   if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t1 - t0;
 }
@@ -94,6 +110,13 @@ int main() {
     run<7>("v_rcp_f64", w);
     run<12>("v_rsq_f64", w);
     run<13>("v_cvt_f64_u32", w);
+    run<14>("v_mad_u64_u32", w);
+    run<15>("v_min3/max3_f32", w);
+    run<16>("v_sqrt_f64", w);
+    run<17>("3-op int ALU", w);
+    run<18>("v_cndmask sgpr", w);
+    run<19>("v_bfi_b32", w);
+    run<20>("v_cmp+v_cndmask", w);
     run<9>("dep v_fma_f64", w);
     run<10>("dep v_fma_f32", w);
   }
