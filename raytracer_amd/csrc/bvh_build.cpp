@@ -22,6 +22,7 @@
 #include <functional>
 #include <limits>
 #include <numeric>
+#include <thread>
 
 #include "device_scene.h"
 #include "scene_validate.h"
@@ -298,6 +299,7 @@ struct Builder {
   uint32_t max_leaf = 1;
   int n_bins = 64;          // SAH bins per axis (ranges too large for the exact sweep)
   size_t sweep_max = 4096;  // ranges up to this many items try every split position
+  bool parallel = true;     // large ranges: the two sides of a split on two threads
   double min_side = 0.0;  // smallest share of the items a side of a split may get
   std::vector<BuildItem>& items;
   std::vector<BinNode>& nodes;
@@ -452,8 +454,48 @@ struct Builder {
     nodes.emplace_back();
     nodes[node_index].left = left;
     nodes[node_index].count = 0;
+    if (parallel && count >= kParallelMin && depth < kParallelDepth) {
+      // the two halves are disjoint ranges of `items`: build the left one on another thread into
+      // vectors of its own and splice both in, in the order the sequential recursion would have
+      // produced (the same tree and the same leaf order; only the numbering of the binary nodes
+      // differs, and collapse_wide renumbers them anyway)
+      std::vector<BinNode> ln(1), rn(1);
+      std::vector<uint32_t> ll, rl;
+      Builder lb(items, ln, ll), rb(items, rn, rl);
+      for (Builder* b : {&lb, &rb}) {
+        b->max_leaf = max_leaf;
+        b->n_bins = n_bins;
+        b->sweep_max = sweep_max;
+        b->min_side = min_side;
+        b->parallel = parallel;
+      }
+      std::thread worker([&] { lb.build(0, begin, mid, depth + 1); });
+      rb.build(0, mid, end, depth + 1);
+      worker.join();
+      splice(left, ln, ll);
+      splice(left + 1, rn, rl);
+      max_depth = std::max(max_depth, std::max(lb.max_depth, rb.max_depth));
+      return;
+    }
     build(left, begin, mid, depth + 1);
     build(left + 1, mid, end, depth + 1);
+  }
+
+  static constexpr size_t kParallelMin = 1u << 15;  // items
+  static constexpr uint32_t kParallelDepth = 3;     // up to eight threads
+
+  // Put a subtree built on its own (root at sub[0], leaf slots counted from 0) at node `slot`.
+  void splice(uint32_t slot, const std::vector<BinNode>& sub, const std::vector<uint32_t>& sub_leaves) {
+    const uint32_t node_base = (uint32_t)nodes.size();  // sub[i], i >= 1, becomes nodes[node_base + i - 1]
+    const uint32_t leaf_base = (uint32_t)leaf_order.size();
+    auto moved = [&](BinNode n) {
+      if (n.count) n.first += leaf_base;
+      else n.left = node_base + n.left - 1u;
+      return n;
+    };
+    nodes[slot] = moved(sub[0]);
+    for (size_t i = 1; i < sub.size(); ++i) nodes.push_back(moved(sub[i]));
+    leaf_order.insert(leaf_order.end(), sub_leaves.begin(), sub_leaves.end());
   }
 };
 
@@ -745,6 +787,7 @@ std::string flatten_scene(const rt_scene& s, FlatScene& out, int& code) {
       if (v >= 2 && v <= 128) b.n_bins = (int)v;
     }
     if (const char* e = getenv("MI355RT_SAH_SWEEP")) b.sweep_max = strtoul(e, nullptr, 10);
+    if (const char* e = getenv("MI355RT_BUILD_THREADS")) b.parallel = strtoul(e, nullptr, 10) != 1;
     if (const char* e = getenv("MI355RT_LEAF_ITEMS")) {
       unsigned long v = strtoul(e, nullptr, 10);
       if (v >= 1 && v <= kMaxLeafItems) b.max_leaf = (uint32_t)v;

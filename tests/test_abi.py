@@ -171,3 +171,17 @@ def test_flat_traversal_equals_reference_topology_on_random_scenes(first_seed):
         ref = o.render(p, po.MODE_ITERATIVE, threads=4)
         flat = o.render(p, po.MODE_FLAT, bvh=(nodes, items), threads=4)
         assert np.array_equal(ref, flat), f"seed {seed}"
+
+
+def test_threaded_build_equals_the_serial_one(monkeypatch):
+    """Ranges of 32768 items and more build their two sides on two threads: same records, same
+    leaf order as the one-thread build (40 000 spheres: two levels of splits run threaded)."""
+    from raytracer_amd.render import build_bvh
+    from raytracer_amd.scene import HostScene
+    scene = HostScene.generate_cover(100, scene_seed=3, width=64, height=36, spp=1, max_depth=5)
+    monkeypatch.setenv("MI355RT_BUILD_THREADS", "1")
+    nodes1, items1, depth1 = build_bvh(scene)
+    monkeypatch.delenv("MI355RT_BUILD_THREADS")
+    nodes2, items2, depth2 = build_bvh(scene)
+    assert len(items1) == 40004 and depth1 == depth2
+    assert np.array_equal(nodes1, nodes2) and np.array_equal(items1, items2)
