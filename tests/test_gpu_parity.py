@@ -241,6 +241,33 @@ def test_headline_size_properties(gpu_ctx, golden_dir):
     assert np.array_equal(part, ref)
 
 
+@pytest.mark.parametrize("name,w,h,spp,window", [("cornell", 1024, 1024, 64, (496, 600, 32, 24)),
+                                                   ("book2", 1920, 1080, 32, (900, 500, 48, 27))])
+def test_other_named_configurations_at_full_size(gpu_ctx, golden_dir, name, w, h, spp, window):
+    """cornell at 1024x1024 (depth 500) and book2 at 1920x1080 (depth 32, shutter open): a window of
+    the full-size frame is the same numbers as that region of the frame, sample ranges add up, and the
+    window matches the CPU oracle (bit for bit without libm calls in the scene, 1e-9 with)."""
+    scene, g = load(golden_dir, name)
+    scene.set_image(w, h)
+    gpu_ctx.upload(scene)
+    depth = scene.max_depth
+    whole = gpu_ctx.render(gpu_ctx.params(w, h, 0, spp, depth, seed=3), dtype=np.float64)
+    lo = gpu_ctx.render(gpu_ctx.params(w, h, 0, spp // 4, depth, seed=3), dtype=np.float64)
+    hi = gpu_ctx.render(gpu_ctx.params(w, h, spp // 4, spp, depth, seed=3), dtype=np.float64)
+    assert np.abs(whole - (lo + hi)).max() <= 1e-12 * np.abs(whole).max()
+    assert np.isfinite(whole).all() and whole.min() >= 0.0
+    part = gpu_ctx.render(gpu_ctx.params(w, h, 0, spp, depth, seed=3, window=window), dtype=np.float64)
+    x0, y0, ww, wh = window
+    assert np.array_equal(part, whole[y0:y0 + wh, x0:x0 + ww])
+    o = po.Oracle(scene.view_ptr)
+    ref = o.render(po.make_params(w, h, 0, spp, depth, 3, window=window), po.MODE_ITERATIVE, threads=8)
+    if name == "cornell":
+        assert np.array_equal(part, ref)
+    else:
+        close = np.isclose(part, ref, rtol=1e-9, atol=1e-12)
+        assert close.mean() > 0.995
+
+
 def test_command_line_renderer_end_to_end(gpu_ctx, tmp_path):
     """scene.ron in, image.png and 'Done in' out (main.rs:49-115), against the library + host resolve."""
     import io
