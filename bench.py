@@ -211,8 +211,8 @@ def main():
             import pyoracle as po
             o = po.Oracle(scene.view_ptr)
             cores = min(16, po.hardware_threads())
-            # bounded sample of the same workload: the whole frame at 2 spp
-            cpu_full_spp = 2
+            # bounded sample of the same workload: the whole frame at 8 spp (~5 s on 16 cores)
+            cpu_full_spp = 8
             pf = po.make_params(args.width, args.height, 0, cpu_full_spp, depth, SEED)
             c0 = time.perf_counter()
             o.render(pf, po.MODE_REFERENCE, threads=cores)
