@@ -463,6 +463,9 @@ shade_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps, uint32_t bounce, uint3
           V3 nb = vmul(beta, so.attenuation);
           pb.beta[path] = make_double4(nb.x, nb.y, nb.z, 0.0);
           pb.ray_o[path] = make_double4(so.p.x, so.p.y, so.p.z, ro.w);
+        } else if (BIN == kAnyBin && !sc.has_lights) {
+          // the fused kernel leaves L unwritten until a path ends when nothing emits
+          pb.radiance[path] = make_double4(0.0, 0.0, 0.0, 0.0);
         }
       }
     }
@@ -634,12 +637,18 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
             pb.ray_o[path] = make_double4(so.p.x, so.p.y, so.p.z, time);
           }
         }
-        // L += add; the first bounce also starts every path's L
-        if (bounce == 0) {
+        if (sc.has_lights) {
+          // L += add; the first bounce also starts every path's L
+          if (bounce == 0) {
+            pb.radiance[path] = make_double4(0.0 + add.x, 0.0 + add.y, 0.0 + add.z, 0.0);
+          } else if (adds) {
+            double4 L = pb.radiance[path];
+            pb.radiance[path] = make_double4(L.x + add.x, L.y + add.y, L.z + add.z, 0.0);
+          }
+        } else if (!survives && !deferred) {
+          // nothing emits: L is 0 until the path ends, so it is written once, where it ends
+          // (a miss adds the background; absorbed or out of depth adds nothing)
           pb.radiance[path] = make_double4(0.0 + add.x, 0.0 + add.y, 0.0 + add.z, 0.0);
-        } else if (adds) {
-          double4 L = pb.radiance[path];
-          pb.radiance[path] = make_double4(L.x + add.x, L.y + add.y, L.z + add.z, 0.0);
         }
       }
       RT_TICK(st, LP_T_SHADE, tick);
@@ -1327,6 +1336,9 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* scene) {
   ds.chain_ranges = ctx->chain_ranges.p;
   ds.n_nodes = (uint32_t)f.nodes.size();
   ds.has_media = f.has_media ? 1u : 0u;
+  ds.has_lights = 0u;
+  for (const DMaterial& m : f.materials)
+    if (m.kind == RT_MAT_DIFFUSE_LIGHT) ds.has_lights = 1u;
   ds.root_code = f.nodes.empty() ? 1u : make_entry(f.nodes[0].a, f.nodes[0].b);
   ds.cam = f.camera;
   std::memcpy(ds.bg, f.background, sizeof ds.bg);

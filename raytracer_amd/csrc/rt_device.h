@@ -32,6 +32,7 @@ struct DeviceScene {
   const uint32_t* chain_ranges;   // {first, count} per chain
   uint32_t n_nodes;
   uint32_t has_media;
+  uint32_t has_lights;  // some material is a DiffuseLight (else a path's L stays 0 until its last event)
   uint32_t root_code;  // traversal entry code of the root record
   rt_camera cam;
   double bg[3];
