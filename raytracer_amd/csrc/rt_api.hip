@@ -5,15 +5,17 @@
 // (path = s_local * n_pixels + pixel, so a wave holds neighbouring pixels of one
 // sample).  Two pipelines produce the same numbers:
 //
-// fused (scenes whose textures are all SolidColor), per pass:
+// fused (the default), per pass:
 //   repeat max_depth times (ray_color's recursion, main.rs:120-140, unrolled):
 //     trace    camera ray (first bounce: jitter + Camera::get_ray, main.rs:87-94,
 //              camera.rs:22-36) or ray load, closest hit over the BVH, hit record,
 //              emitted, scatter, attenuation; survivors go to the next live queue.
+//              Hits on materials with procedural or image textures are queued instead.
 //              Once few paths are left, one launch finishes all their bounces.
+//     shade    (scenes with such textures) the queued hits, any material kind
 //   resolve  per pixel, adds the S path radiances in sample order (main.rs:97)
 //
-// binned (any scene; forced by RT_FLAG_BINNED), per pass:
+// binned (RT_FLAG_BINNED), per pass:
 //   raygen   jitter + Camera::get_ray
 //   repeat max_depth times:
 //     extend   closest hit, then each live path is appended to the bin of what it
