@@ -559,13 +559,17 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
   Stats st;
   if (STATS) st.clear();
   const uint32_t stride = gridDim.x * (uint32_t)BLOCK;
-  // a wave's 64 rays per trip; the trip count differs between the waves of a workgroup
+  // a wave's 64 rays per trip; the trip count differs between the waves of a workgroup.
+  // The queue entry of the next trip is fetched a trip ahead, so that a trip starts with
+  // one round trip to memory (the ray) instead of two.
+  const uint32_t first_i = blockIdx.x * (uint32_t)BLOCK + threadIdx.x;
+  uint32_t path_ahead = first_i < n_live ? live.path(first_i) : 0u;
   for (uint32_t base = blockIdx.x * (uint32_t)BLOCK + (threadIdx.x & ~63u); base < n_live;
        base += stride) {
     const uint32_t i = base + (threadIdx.x & 63u);
     bool valid = i < n_live;
-    uint32_t path = 0;
-    if (valid) path = live.path(i);
+    uint32_t path = path_ahead;
+    if (i + stride < n_live && i + stride > i) path_ahead = live.path(i + stride);
     uint32_t bounce = first_bounce;
     bool survives, deferred = false;
     do {
