@@ -538,15 +538,22 @@ RT_DEV void wave_flush(const uint32_t* stage, uint32_t n, uint32_t* g_counter, u
 #ifndef RT_TRACE_MEDIA_WAVES
 #define RT_TRACE_MEDIA_WAVES 3
 #endif
-template <int BLOCK, bool STATS, bool MEDIA, bool OVERFLOW, bool TAIL>
+// MODE: kTraceBounce (one bounce >= 1 of the live queue), kTraceTail, kTraceFirst (bounce 0: the
+// camera rays of every path of the pass; a variant of its own so that the other bounces do not
+// carry the camera block in scalar registers: that pressure showed as scalar spills all
+// through the per-trip code).
+enum { kTraceBounce = 0, kTraceTail = 1, kTraceFirst = 2 };
+template <int BLOCK, bool STATS, bool MEDIA, bool OVERFLOW, int MODE>
 __global__ void __launch_bounds__(BLOCK, MEDIA ? RT_TRACE_MEDIA_WAVES : 4)  // waves per SIMD to fit registers for
-trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_t first_bounce,
+trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_t first_bounce_arg,
              uint32_t max_depth, unsigned long long* g_stats) {
+  constexpr bool TAIL = MODE == kTraceTail, FIRST = MODE == kTraceFirst;
+  const uint32_t first_bounce = FIRST ? 0u : first_bounce_arg;
   extern __shared__ __align__(16) char smem[];
   __shared__ uint32_t s_next[(BLOCK / 64) * kWaveStage];
   constexpr bool DEFER = !TAIL;  // (the tail shades everything in place; the host runs none for textured scenes)
   __shared__ uint32_t s_defer[DEFER ? (BLOCK / 64) * kDeferStage : 1];
-  const LiveIn live = live_in(pb, first_bounce, ps.n_paths);
+  const LiveIn live = live_in(pb, first_bounce, ps.n_paths);  // (bounce 0: no queue, path = index)
   uint32_t* next_live = next_live_queue(pb, first_bounce, blockIdx.x);
   uint32_t* next_count = next_live_counter(pb, first_bounce, blockIdx.x);
   uint32_t* counters = pb.counters + (size_t)first_bounce * kCounterStride;
@@ -563,13 +570,14 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
   // The queue entry of the next trip is fetched a trip ahead, so that a trip starts with
   // one round trip to memory (the ray) instead of two.
   const uint32_t first_i = blockIdx.x * (uint32_t)BLOCK + threadIdx.x;
-  uint32_t path_ahead = first_i < n_live ? live.path(first_i) : 0u;
+  uint32_t path_ahead = FIRST ? first_i : first_i < n_live ? live.path(first_i) : 0u;
   for (uint32_t base = blockIdx.x * (uint32_t)BLOCK + (threadIdx.x & ~63u); base < n_live;
        base += stride) {
     const uint32_t i = base + (threadIdx.x & 63u);
     bool valid = i < n_live;
     uint32_t path = path_ahead;
-    if (i + stride < n_live && i + stride > i) path_ahead = live.path(i + stride);
+    if (FIRST) path_ahead = i + stride;
+    else if (i + stride < n_live && i + stride > i) path_ahead = live.path(i + stride);
     uint32_t bounce = first_bounce;
     bool survives, deferred = false;
     do {
@@ -589,7 +597,7 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
         V3 o, d;
         double time;
         // the first bounce makes its own camera ray
-        if (bounce == 0) {
+        if (FIRST) {
           camera_ray(sc, ps, x, y, key, o, d, time);
         } else {
           double4 ro = pb.ray_o[path];
@@ -605,7 +613,7 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
         RT_TICK(st, LP_T_TRAVERSE, tick);
         // ... and starts from beta = 1, L = 0
         V3 beta = v3(1.0, 1.0, 1.0);
-        if (bounce != 0) {
+        if (!FIRST) {
           double4 bt = pb.beta[path];
           beta = v3(bt.x, bt.y, bt.z);
         }
@@ -622,7 +630,7 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
           pb.ray_o[path] = make_double4(o.x, o.y, o.z, time);
           pb.ray_d[path] = make_double4(d.x, d.y, d.z, h.t);
           pb.hit_item[path] = h.item;
-          if (bounce == 0) pb.beta[path] = make_double4(1.0, 1.0, 1.0, 0.0);
+          if (FIRST) pb.beta[path] = make_double4(1.0, 1.0, 1.0, 0.0);
         } else {
           stat<STATS>(st, RT_STAT_HITS);
           RT_LP(st, LP_SHADE);
@@ -645,7 +653,7 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
         }
         if (sc.has_lights) {
           // L += add; the first bounce also starts every path's L
-          if (bounce == 0) {
+          if (FIRST) {
             pb.radiance[path] = make_double4(0.0 + add.x, 0.0 + add.y, 0.0 + add.z, 0.0);
           } else if (adds) {
             double4 L = pb.radiance[path];
@@ -992,6 +1000,13 @@ LdsLayout plan_lds(const FlatScene& f, uint32_t block, uint32_t budget, uint32_t
   return l;
 }
 
+// A run-time trace mode as a compile-time one.
+template <typename F>
+auto with_mode(int mode, F&& f) {
+  if (mode == kTraceTail) return f(std::integral_constant<int, kTraceTail>{});
+  if (mode == kTraceFirst) return f(std::integral_constant<int, kTraceFirst>{});
+  return f(std::integral_constant<int, kTraceBounce>{});
+}
 // A run-time bool as a compile-time one: f(std::true_type) or f(std::false_type).
 template <typename F>
 auto with_bool(bool v, F&& f) {
@@ -1006,7 +1021,7 @@ void launch_trace_block(rt_ctx* ctx, bool stats, bool media, bool tail, uint32_t
   with_bool(stats, [&](auto S) {
     return with_bool(media, [&](auto M) {
       return with_bool(l.overflow != nullptr, [&](auto O) {
-        return with_bool(tail, [&](auto T) {
+        return with_mode(tail ? kTraceTail : b == 0 ? kTraceFirst : kTraceBounce, [&](auto T) {
           trace_kernel<BLOCK, decltype(S)::value, decltype(M)::value, decltype(O)::value,
                        decltype(T)::value>
               <<<grid, BLOCK, l.bytes, ctx->stream>>>(ctx->ds, l, pb, ps, b, max_depth, gs);
@@ -1039,11 +1054,11 @@ template <int BLOCK>
 hipError_t allow_trace_lds(int bytes) {
   const hipFuncAttribute attr = hipFuncAttributeMaxDynamicSharedMemorySize;
   hipError_t e = hipSuccess;
-  for (int v = 0; v < 16 && e == hipSuccess; ++v)
+  for (int v = 0; v < 24 && e == hipSuccess; ++v)
     e = with_bool(v & 1, [&](auto S) {
       return with_bool(v & 2, [&](auto M) {
         return with_bool(v & 4, [&](auto O) {
-          return with_bool(v & 8, [&](auto T) {
+          return with_mode(v >> 3, [&](auto T) {
             return hipFuncSetAttribute(
                 (const void*)trace_kernel<BLOCK, decltype(S)::value, decltype(M)::value,
                                           decltype(O)::value, decltype(T)::value>,
