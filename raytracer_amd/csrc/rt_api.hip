@@ -343,15 +343,21 @@ RT_DEV ShadeOut shade_begin(const DeviceScene& sc, uint32_t kind, const DPrim& p
   bool want_uv = textured && ((pr.kind >> 11) & 1u);
   Record rec = make_record<!SOLID>(sc, pr, o, d, time, t, want_uv);
   out.p = rec.p;
+  // Metal and Dielectric both start from the unit direction and its mirror image; a wave that
+  // holds both kinds computes them in one go instead of once per branch.
+  V3 ud = v3(0.0, 0.0, 0.0), mirrored = ud;
+  if (kind == RT_MAT_METAL || kind == RT_MAT_DIELECTRIC) {
+    ud = vunit(d);
+    mirrored = vreflect(ud, rec.normal);
+  }
   if (kind == RT_MAT_LAMBERTIAN) {  // lambertian.rs:13-25
     out.direction = rec.normal;
     out.attenuation = SOLID ? v3(m.albedo) : texture_value<STATS>(sc, m.texture, rec.u, rec.v, rec.p, st);
     out.scattered = true;
     out.needs_vector = true;
   } else if (kind == RT_MAT_METAL) {  // metal.rs:12-28
-    V3 reflected = vreflect(vunit(d), rec.normal);
-    if (vdot(reflected, rec.normal) > 0.0) {
-      out.direction = reflected;
+    if (vdot(mirrored, rec.normal) > 0.0) {
+      out.direction = mirrored;
       out.fuzz = m.param;
       out.scattered = true;
       out.needs_vector = true;
@@ -359,14 +365,12 @@ RT_DEV ShadeOut shade_begin(const DeviceScene& sc, uint32_t kind, const DPrim& p
     out.attenuation = v3(m.albedo);
   } else if (kind == RT_MAT_DIELECTRIC) {  // dielectric.rs:14-38
     double ratio = rec.front ? 1.0 / m.param : m.param;
-    V3 ud = vunit(d);
     double cos_theta = fmin(vdot(vneg(ud), rec.normal), 1.0);
     double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
     bool cannot_refract = ratio * sin_theta > 1.0;
     u32x4 fb = draw(key, DRAW_FRESNEL, 0);
     bool should_reflect = reflectance(cos_theta, ratio) > u01_53(fb.x, fb.y);
-    out.direction = (cannot_refract || should_reflect) ? vreflect(ud, rec.normal)
-                                                       : vrefract(ud, rec.normal, ratio);
+    out.direction = (cannot_refract || should_reflect) ? mirrored : vrefract(ud, rec.normal, ratio);
     out.attenuation = v3(1.0, 1.0, 1.0);
     out.scattered = true;
   } else if (kind == RT_MAT_DIFFUSE_LIGHT) {  // emissive.rs:10-12; never scatters
