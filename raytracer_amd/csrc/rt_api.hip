@@ -287,12 +287,16 @@ extend_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32
       if (mine) s_bin[k * kStageCap + slot] = path;
     }
     __syncthreads();
+    // every wave reads the same counts: none may append again before all have read them
+    uint32_t staged[kBins];
+#pragma unroll
+    for (uint32_t k = 0; k < kBins; ++k) staged[k] = s_bin_count[k];
+    __syncthreads();
 #pragma unroll
     for (uint32_t k = 0; k < kBins; ++k) {
-      uint32_t n = s_bin_count[k];
-      if (n >= kFlushAt)
+      if (staged[k] >= kFlushAt)
         stage_flush(s_bin + k * kStageCap, &s_bin_count[k], &s_word, counters + k,
-                    pb.bins + (size_t)k * pb.capacity, n);
+                    pb.bins + (size_t)k * pb.capacity, staged[k]);
     }
   }
 #pragma unroll
@@ -486,6 +490,7 @@ shade_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps, uint32_t bounce, uint3
       if (survives) s_next[slot] = path;
       __syncthreads();
       uint32_t n = s_next_count;
+      __syncthreads();  // (no wave appends again before all have read n)
       if (n >= kFlushAt) stage_flush(s_next, &s_next_count, &s_word, next_count, next_live, n);
     }
   }
@@ -870,6 +875,7 @@ struct rt_ctx {
   uint32_t tail_paths = 1u << 18;  // fused pipeline: at most this many live paths finish in one launch
   DeviceArray<uint32_t> stack_overflow;
   std::vector<hipEvent_t> events;  // RT_FLAG_TIMING: three per bounce (before extend, between, after shade)
+  DeviceArray<unsigned char> staging;     // device side of host-buffer results (rt_render, rt_first_hit)
 };
 
 namespace {
@@ -1096,8 +1102,9 @@ hipError_t allow_extend_lds(int bytes) {
   return e;
 }
 
-// Render the sample range into ctx->accum (f64 sums, window-sized).
-int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats) {
+// Render the sample range into f64 sums (window-sized) on the device; *accum_out names them.
+int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats, double** accum_out) {
+  const bool in_scratch = false;
   if (!ctx) return RT_ERR_INVALID;
   if (!p) return fail(ctx, RT_ERR_INVALID, "null params");
   if (!ctx->have_scene) return fail(ctx, RT_ERR_INVALID, "no scene uploaded");
@@ -1107,8 +1114,8 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats) {
   int rc = check_window(ctx, p->width, p->height, &p->window, ps);
   if (rc != RT_OK) return rc;
   ps.seed = p->seed;
-  const bool want_stats = (p->flags & RT_FLAG_STATS) && stats;
-  const bool want_timing = (p->flags & RT_FLAG_TIMING) && stats;
+  const bool want_stats = (p->flags & RT_FLAG_STATS) && stats && !in_scratch;
+  const bool want_timing = (p->flags & RT_FLAG_TIMING) && stats && !in_scratch;
   size_t n_events = 0;
   double extend_ms = 0.0, shade_ms = 0.0;
   uint64_t timed_launches = 0;
@@ -1140,12 +1147,33 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats) {
   if (n_pix > ctx->max_paths)
     return fail(ctx, RT_ERR_LIMIT, "window has more pixels than max_paths_in_flight");
 
-  if (ctx->accum.n < n_pix * 3) {
-    ctx->accum.release();
-    RT_HIP(ctx, hipMalloc((void**)&ctx->accum.p, n_pix * 3 * sizeof(double)));
-    ctx->accum.n = n_pix * 3;
+  // the MEDIA kernels carry the rare cases: constant media and records tied to the reference's box chain
+  const bool media = ctx->flat.has_media || !ctx->flat.chain_ranges.empty();
+  const bool solid = ctx->solid;
+  // traversal and scatter run fused, with the hits on procedural or image textures deferred
+  // to a shade kernel of their own; RT_FLAG_BINNED forces the extend / shade-per-material pipeline
+  const bool fused = !(p->flags & RT_FLAG_BINNED);
+  const bool defer = fused && ctx->flat.defers;
+  const bool general = ctx->general;
+  const uint32_t queues = fused ? (defer ? 1u : 0u) : kBins;
+  uint32_t bins_present = 1u;
+  for (const DMaterial& m : ctx->flat.materials) bins_present |= 2u << m.kind;
+
+  PathBuffers scratch_pb{};
+  double* accum = nullptr;
+  uint32_t per_pass = 0;
+  {
+    if (ctx->accum.n < n_pix * 3) {
+      ctx->accum.release();
+      RT_HIP(ctx, hipMalloc((void**)&ctx->accum.p, n_pix * 3 * sizeof(double)));
+      ctx->accum.n = n_pix * 3;
+    }
+    accum = ctx->accum.p;
+    per_pass = (uint32_t)std::min<uint64_t>(ctx->max_paths / n_pix, n_samples);
+    if (per_pass == 0) per_pass = 1;
   }
-  RT_HIP(ctx, hipMemsetAsync(ctx->accum.p, 0, n_pix * 3 * sizeof(double), ctx->stream));
+  *accum_out = accum;
+  RT_HIP(ctx, hipMemsetAsync(accum, 0, n_pix * 3 * sizeof(double), ctx->stream));
   if (want_stats)
     RT_HIP(ctx, hipMemsetAsync(ctx->stats.p, 0, RT_STAT_COUNT * sizeof(unsigned long long),
                                ctx->stream));
@@ -1156,22 +1184,12 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats) {
     return RT_OK;
   }
 
-  uint32_t per_pass = (uint32_t)std::min<uint64_t>(ctx->max_paths / n_pix, n_samples);
-  if (per_pass == 0) per_pass = 1;
-  const PathBuffers& pb = ctx->pb;
+  if (!in_scratch) {
+    rc = ensure_paths(ctx, n_pix * per_pass, p->max_depth, queues);
+    if (rc != RT_OK) return rc;
+  }
+  const PathBuffers& pb = in_scratch ? scratch_pb : ctx->pb;
   const uint32_t max_grid = ctx->n_cus * ctx->blocks_per_cu;
-  // the MEDIA kernels carry the rare cases: constant media and records tied to the reference's box chain
-  const bool media = ctx->flat.has_media || !ctx->flat.chain_ranges.empty();
-  const bool solid = ctx->solid;
-  // traversal and scatter run fused, with the hits on procedural or image textures deferred
-  // to a shade kernel of their own; RT_FLAG_BINNED forces the extend / shade-per-material pipeline
-  const bool fused = !(p->flags & RT_FLAG_BINNED);
-  const bool defer = fused && ctx->flat.defers;
-  const bool general = ctx->general;
-  uint32_t bins_present = 1u;
-  for (const DMaterial& m : ctx->flat.materials) bins_present |= 2u << m.kind;
-  rc = ensure_paths(ctx, n_pix * per_pass, p->max_depth, fused ? (defer ? 1u : 0u) : kBins);
-  if (rc != RT_OK) return rc;
 
   for (uint32_t done = 0; done < n_samples; done += per_pass) {
     ps.samples = std::min(per_pass, n_samples - done);
@@ -1240,7 +1258,7 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats) {
         }
       }
     }
-    resolve_kernel<<<blocks_for(n_pix), kBlock, 0, ctx->stream>>>(pb, ps, ctx->accum.p);
+    resolve_kernel<<<blocks_for(n_pix), kBlock, 0, ctx->stream>>>(pb, ps, accum);
   }
   RT_HIP(ctx, hipGetLastError());
   RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1281,7 +1299,8 @@ int rt_create(const rt_config* cfg, rt_ctx** out) {
       hipStreamCreate(&ctx->stream) != hipSuccess ||
       hipMalloc((void**)&ctx->stats.p, RT_STAT_COUNT * sizeof(unsigned long long)) != hipSuccess ||
       hipHostMalloc((void**)&ctx->h_probe, kCounterStride * sizeof(uint32_t)) != hipSuccess) {
-    delete ctx;
+    (void)hipGetLastError();
+    rt_destroy(ctx);  // frees whatever was created before the failure
     return RT_ERR_DEVICE;
   }
   ctx->n_cus = (uint32_t)prop.multiProcessorCount;
@@ -1296,6 +1315,11 @@ int rt_create(const rt_config* cfg, rt_ctx** out) {
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
     uint64_t fit = (uint64_t)(free_b / 4) / 224u;
     ctx->max_paths = std::min<uint64_t>(std::max<uint64_t>(fit, 1ull << 22), 1ull << 27);
+  }
+  // path indices and the grid-stride loops over them are 32-bit
+  if (ctx->max_paths > (1ull << 31)) {
+    rt_destroy(ctx);
+    return RT_ERR_LIMIT;
   }
   *out = ctx;
   return RT_OK;
@@ -1441,50 +1465,67 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* scene) {
 int rt_render_f64(rt_ctx* ctx, const rt_render_params* p, double* rgb_sum, uint64_t* stats) {
   if (!ctx) return RT_ERR_INVALID;
   if (!rgb_sum) return fail(ctx, RT_ERR_INVALID, "null output");
-  int rc = render_into_accum(ctx, p, stats);
+  double* accum = nullptr;
+  int rc = render_into_accum(ctx, p, stats, &accum);
   if (rc != RT_OK) return rc;
   PassInfo ps{};
   check_window(ctx, p->width, p->height, &p->window, ps);
-  RT_HIP(ctx, hipMemcpy(rgb_sum, ctx->accum.p, (size_t)ps.n_pixels * 3 * sizeof(double),
+  RT_HIP(ctx, hipMemcpy(rgb_sum, accum, (size_t)ps.n_pixels * 3 * sizeof(double),
                         hipMemcpyDeviceToHost));
+  return RT_OK;
+}
+
+static int output_on_device(rt_ctx* ctx, const void* d_out) {
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, d_out) != hipSuccess ||
+      attr.type != hipMemoryTypeDevice || attr.device != ctx->device) {
+    (void)hipGetLastError();
+    return fail(ctx, RT_ERR_INVALID, "output is not device memory of the context's device");
+  }
   return RT_OK;
 }
 
 int rt_render_device(rt_ctx* ctx, const rt_render_params* p, float* d_rgb_sum, uint64_t* stats) {
   if (!ctx) return RT_ERR_INVALID;
   if (!d_rgb_sum) return fail(ctx, RT_ERR_INVALID, "null output");
-  hipPointerAttribute_t attr;
-  if (hipPointerGetAttributes(&attr, d_rgb_sum) != hipSuccess ||
-      attr.type != hipMemoryTypeDevice || attr.device != ctx->device) {
-    (void)hipGetLastError();
-    return fail(ctx, RT_ERR_INVALID, "output is not device memory of the context's device");
-  }
-  int rc = render_into_accum(ctx, p, stats);
+  int rc = output_on_device(ctx, d_rgb_sum);
+  if (rc != RT_OK) return rc;
+  double* accum = nullptr;
+  rc = render_into_accum(ctx, p, stats, &accum);
   if (rc != RT_OK) return rc;
   PassInfo ps{};
   check_window(ctx, p->width, p->height, &p->window, ps);
   uint64_t n = (uint64_t)ps.n_pixels * 3;
-  to_float_kernel<<<blocks_for(n), kBlock, 0, ctx->stream>>>(ctx->accum.p, d_rgb_sum, n);
+  to_float_kernel<<<blocks_for(n), kBlock, 0, ctx->stream>>>(accum, d_rgb_sum, n);
   RT_HIP(ctx, hipGetLastError());
   RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return RT_OK;
+}
+
+// Device-side staging for the entry points that hand results over in host buffers; kept by
+// the context and grown on demand, so repeated calls do not allocate.
+static int ensure_staging(rt_ctx* ctx, size_t bytes) {
+  if (ctx->staging.n >= bytes) return RT_OK;
+  ctx->staging.release();
+  RT_HIP(ctx, hipMalloc((void**)&ctx->staging.p, bytes));
+  ctx->staging.n = bytes;
   return RT_OK;
 }
 
 int rt_render(rt_ctx* ctx, const rt_render_params* p, float* rgb_sum, uint64_t* stats) {
   if (!ctx) return RT_ERR_INVALID;
   if (!rgb_sum) return fail(ctx, RT_ERR_INVALID, "null output");
-  int rc = render_into_accum(ctx, p, stats);
+  double* accum = nullptr;
+  int rc = render_into_accum(ctx, p, stats, &accum);
   if (rc != RT_OK) return rc;
   PassInfo ps{};
   check_window(ctx, p->width, p->height, &p->window, ps);
   uint64_t n = (uint64_t)ps.n_pixels * 3;
-  float* d_out = nullptr;
-  RT_HIP(ctx, hipMalloc((void**)&d_out, n * sizeof(float)));
-  to_float_kernel<<<blocks_for(n), kBlock, 0, ctx->stream>>>(ctx->accum.p, d_out, n);
-  hipError_t e = hipMemcpyAsync(rgb_sum, d_out, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  (void)hipFree(d_out);
-  if (e != hipSuccess) return fail(ctx, RT_ERR_DEVICE, hipGetErrorString(e));
+  if ((rc = ensure_staging(ctx, n * sizeof(float))) != RT_OK) return rc;
+  float* d_out = (float*)ctx->staging.p;
+  to_float_kernel<<<blocks_for(n), kBlock, 0, ctx->stream>>>(accum, d_out, n);
+  RT_HIP(ctx, hipMemcpyAsync(rgb_sum, d_out, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return RT_OK;
 }
 
@@ -1498,31 +1539,24 @@ int rt_first_hit(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_window* 
   int rc = check_window(ctx, width, height, window, ps);
   if (rc != RT_OK) return rc;
   size_t n = ps.n_pixels;
-  uint32_t* d_id = nullptr;
-  double *d_t = nullptr, *d_n = nullptr;
-  hipError_t e = hipMalloc((void**)&d_id, n * sizeof(uint32_t));
-  if (e == hipSuccess) e = hipMalloc((void**)&d_t, n * sizeof(double));
-  if (e == hipSuccess) e = hipMalloc((void**)&d_n, n * 3 * sizeof(double));
-  if (e == hipSuccess) {
-    const uint32_t fgrid = std::min(blocks_for(n), ctx->n_cus * ctx->blocks_per_cu);
-    with_bool(!ctx->flat.chain_ranges.empty(), [&](auto C) {
-      return with_bool(ctx->lds.overflow != nullptr, [&](auto O) {
-        first_hit_kernel<decltype(C)::value, decltype(O)::value>
-            <<<fgrid, kBlock, ctx->lds.bytes, ctx->stream>>>(ctx->ds, ctx->lds, ps, d_id, d_t, d_n);
-        return 0;
-      });
+  // staging: normals (3 f64), t (f64), id (u32) per pixel, in that order (alignment)
+  if ((rc = ensure_staging(ctx, n * (4 * sizeof(double) + sizeof(uint32_t)))) != RT_OK) return rc;
+  double* d_n = (double*)ctx->staging.p;
+  double* d_t = d_n + 3 * n;
+  uint32_t* d_id = (uint32_t*)(d_t + n);
+  const uint32_t fgrid = std::min(blocks_for(n), ctx->n_cus * ctx->blocks_per_cu);
+  with_bool(!ctx->flat.chain_ranges.empty(), [&](auto C) {
+    return with_bool(ctx->lds.overflow != nullptr, [&](auto O) {
+      first_hit_kernel<decltype(C)::value, decltype(O)::value>
+          <<<fgrid, kBlock, ctx->lds.bytes, ctx->stream>>>(ctx->ds, ctx->lds, ps, d_id, d_t, d_n);
+      return 0;
     });
-    e = hipGetLastError();
-  }
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  if (e == hipSuccess) e = hipMemcpy(id, d_id, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
-  if (e == hipSuccess) e = hipMemcpy(t, d_t, n * sizeof(double), hipMemcpyDeviceToHost);
-  if (e == hipSuccess) e = hipMemcpy(normal, d_n, n * 3 * sizeof(double), hipMemcpyDeviceToHost);
-  if (d_id) (void)hipFree(d_id);
-  if (d_t) (void)hipFree(d_t);
-  if (d_n) (void)hipFree(d_n);
-  if (e != hipSuccess)
-    return fail(ctx, e == hipErrorOutOfMemory ? RT_ERR_NOMEM : RT_ERR_DEVICE, hipGetErrorString(e));
+  });
+  RT_HIP(ctx, hipGetLastError());
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  RT_HIP(ctx, hipMemcpy(id, d_id, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  RT_HIP(ctx, hipMemcpy(t, d_t, n * sizeof(double), hipMemcpyDeviceToHost));
+  RT_HIP(ctx, hipMemcpy(normal, d_n, n * 3 * sizeof(double), hipMemcpyDeviceToHost));
   return RT_OK;
 }
 
@@ -1587,6 +1621,7 @@ void rt_destroy(rt_ctx* ctx) {
   ctx->stack_overflow.release();
   ctx->chain_ranges.release();
   ctx->accum.release();
+  ctx->staging.release();
   ctx->stats.release();
   if (ctx->h_probe) (void)hipHostFree(ctx->h_probe);
   for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
