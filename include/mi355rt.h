@@ -310,6 +310,19 @@ int rt_render_f64(rt_ctx* ctx, const rt_render_params* p, double* rgb_sum, uint6
  * collective will reduce); the call returns after the device work completed. */
 int rt_render_device(rt_ctx* ctx, const rt_render_params* p, float* d_rgb_sum, uint64_t* stats);
 
+/* No counterpart in the reference.  For callers that cannot allocate device memory while
+ * they render (code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc): the same sums as rt_render_device, with every intermediate buffer (path state,
+ * live-path queues, counters, the f64 sums) in a fixed RT_NOALLOC_SCRATCH_BYTES array that is
+ * part of the library's code object, one copy per GPU.  The call allocates and frees nothing.
+ * Limits: a window whose single-sample pass does not fit the array is refused with
+ * RT_ERR_LIMIT (about 2^18 pixels at depth 50); no statistics or launch timing.  Every call on
+ * a GPU shares that GPU's array, whichever context makes it: calls that overlap on one GPU
+ * race, and the array keeps the last call's contents between calls (each call clears what it
+ * needs at zero). */
+#define RT_NOALLOC_SCRATCH_BYTES (64u << 20)
+int rt_render_device_noalloc(rt_ctx* ctx, const rt_render_params* p, float* d_rgb_sum);
+
 /* Deterministic parity pass: pinhole rays through pixel centres
  * (u=(x+0.5)/(w-1), v=((h-y)+0.5)/(h-1), lens offset 0, time = shutter start),
  * world.hit(ray, 0.001..inf) (src/main.rs:123) with constant media left out.

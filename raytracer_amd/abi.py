@@ -146,7 +146,7 @@ HOST_SYMBOLS = [
 ]
 DEVICE_SYMBOLS = [
     "rt_create", "rt_upload_scene", "rt_render", "rt_render_f64", "rt_render_device",
-    "rt_first_hit", "rt_bvh_build", "rt_bvh_info", "rt_bvh_copy", "rt_bvh_free", "rt_last_error",
+    "rt_render_device_noalloc", "rt_first_hit", "rt_bvh_build", "rt_bvh_info", "rt_bvh_copy", "rt_bvh_free", "rt_last_error",
     "rt_destroy",
 ]
 
@@ -208,6 +208,7 @@ def device_lib():
     L.rt_render.argtypes = [vp, C.POINTER(RenderParams), vp, vp]
     L.rt_render_f64.argtypes = [vp, C.POINTER(RenderParams), vp, vp]
     L.rt_render_device.argtypes = [vp, C.POINTER(RenderParams), vp, vp]
+    L.rt_render_device_noalloc.argtypes = [vp, C.POINTER(RenderParams), vp]
     L.rt_first_hit.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(Window), vp, vp, vp]
     L.rt_bvh_build.argtypes = [C.POINTER(Scene), C.POINTER(vp)]
     L.rt_bvh_info.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),

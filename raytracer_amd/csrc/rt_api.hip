@@ -43,6 +43,12 @@
 
 using namespace rt;
 
+// Path state, queues, counters and the f64 sums of rt_render_device_noalloc: one array per GPU,
+// part of the code object, so the entry point never allocates.  Host code must not use this
+// name as an address: rt_create asks the runtime for each device's copy (hipGetSymbolAddress)
+// and everything below works on that pointer.
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES];
+
 namespace {
 
 const int kBlock = 256;
@@ -876,6 +882,7 @@ struct rt_ctx {
   DeviceArray<uint32_t> stack_overflow;
   std::vector<hipEvent_t> events;  // RT_FLAG_TIMING: three per bounce (before extend, between, after shade)
   DeviceArray<unsigned char> staging;     // device side of host-buffer results (rt_render, rt_first_hit)
+  unsigned char* scratch_ptr = nullptr;  // this device's copy of `scratch` (rt_render_device_noalloc)
 };
 
 namespace {
@@ -951,6 +958,50 @@ int ensure_paths(rt_ctx* ctx, uint64_t capacity, uint32_t max_depth, uint32_t qu
                           (size_t)max_depth * kCounterStride * sizeof(uint32_t)));
     ctx->counters_depth = max_depth;
   }
+  return RT_OK;
+}
+
+// The same buffers as ensure_paths makes, laid out in this device's copy of `scratch`
+// (256-byte aligned pieces), plus the window's f64 sums.  Picks the largest number of samples
+// per pass that fits; fails when not even one sample of every window pixel does.
+int carve_scratch(rt_ctx* ctx, uint64_t n_pix, uint32_t n_samples, uint32_t max_depth, uint32_t queues,
+                  PathBuffers& pb, double*& accum, uint32_t& per_pass) {
+  auto up = [](uint64_t b) { return (b + 255u) & ~(uint64_t)255u; };
+  const uint64_t fixed = up(n_pix * 3 * sizeof(double)) +
+                         up((uint64_t)max_depth * kCounterStride * sizeof(uint32_t));
+  auto need = [&](uint64_t cap) {
+    return fixed + 4 * up(cap * sizeof(double4)) + 2 * up(cap * kSubQueues * sizeof(uint32_t)) +
+           (queues ? up(cap * sizeof(uint32_t)) + up(cap * queues * sizeof(uint32_t)) : 0);
+  };
+  uint64_t s = std::max<uint32_t>(n_samples, 1u);
+  while (s > 1 && (n_pix * s > ctx->max_paths || need(n_pix * s) > RT_NOALLOC_SCRATCH_BYTES)) s = (s + 1) / 2;
+  if (need(n_pix * s) > RT_NOALLOC_SCRATCH_BYTES)
+    return fail(ctx, RT_ERR_LIMIT,
+                "rt_render_device_noalloc: a window of " + std::to_string(n_pix) + " pixels at depth " +
+                    std::to_string(max_depth) + " needs " + std::to_string(need(n_pix)) +
+                    " bytes of scratch, the limit is " + std::to_string(RT_NOALLOC_SCRATCH_BYTES));
+  const uint64_t cap = n_pix * s;
+  unsigned char* at = ctx->scratch_ptr;
+  auto take = [&](uint64_t bytes) {
+    unsigned char* r = at;
+    at += up(bytes);
+    return r;
+  };
+  pb = PathBuffers{};
+  accum = (double*)take(n_pix * 3 * sizeof(double));
+  pb.counters = (uint32_t*)take((uint64_t)max_depth * kCounterStride * sizeof(uint32_t));
+  pb.ray_o = (double4*)take(cap * sizeof(double4));
+  pb.ray_d = (double4*)take(cap * sizeof(double4));
+  pb.beta = (double4*)take(cap * sizeof(double4));
+  pb.radiance = (double4*)take(cap * sizeof(double4));
+  pb.live[0] = (uint32_t*)take(cap * kSubQueues * sizeof(uint32_t));
+  pb.live[1] = (uint32_t*)take(cap * kSubQueues * sizeof(uint32_t));
+  if (queues) {
+    pb.hit_item = (uint32_t*)take(cap * sizeof(uint32_t));
+    pb.bins = (uint32_t*)take(cap * queues * sizeof(uint32_t));
+  }
+  pb.capacity = cap;
+  per_pass = (uint32_t)s;
   return RT_OK;
 }
 
@@ -1103,8 +1154,10 @@ hipError_t allow_extend_lds(int bytes) {
 }
 
 // Render the sample range into f64 sums (window-sized) on the device; *accum_out names them.
-int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats, double** accum_out) {
-  const bool in_scratch = false;
+// in_scratch: every buffer comes out of this device's `scratch` array and nothing is allocated
+// (no statistics, no launch timing: their events would have to be created).
+int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats, double** accum_out,
+                      bool in_scratch = false) {
   if (!ctx) return RT_ERR_INVALID;
   if (!p) return fail(ctx, RT_ERR_INVALID, "null params");
   if (!ctx->have_scene) return fail(ctx, RT_ERR_INVALID, "no scene uploaded");
@@ -1162,7 +1215,10 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats, d
   PathBuffers scratch_pb{};
   double* accum = nullptr;
   uint32_t per_pass = 0;
-  {
+  if (in_scratch) {
+    rc = carve_scratch(ctx, n_pix, n_samples, std::max(p->max_depth, 1u), queues, scratch_pb, accum, per_pass);
+    if (rc != RT_OK) return rc;
+  } else {
     if (ctx->accum.n < n_pix * 3) {
       ctx->accum.release();
       RT_HIP(ctx, hipMalloc((void**)&ctx->accum.p, n_pix * 3 * sizeof(double)));
@@ -1294,11 +1350,14 @@ int rt_create(const rt_config* cfg, rt_ctx** out) {
     return RT_ERR_DEVICE;  // no usable HIP device: there is no other way to render
   }
   hipDeviceProp_t prop;
+  // the address of this device's copy of the no-allocation scratch array, with the device current
   if (hipSetDevice(ctx->device) != hipSuccess ||
       hipGetDeviceProperties(&prop, ctx->device) != hipSuccess ||
       hipStreamCreate(&ctx->stream) != hipSuccess ||
       hipMalloc((void**)&ctx->stats.p, RT_STAT_COUNT * sizeof(unsigned long long)) != hipSuccess ||
-      hipHostMalloc((void**)&ctx->h_probe, kCounterStride * sizeof(uint32_t)) != hipSuccess) {
+      hipHostMalloc((void**)&ctx->h_probe, kCounterStride * sizeof(uint32_t)) != hipSuccess ||
+      hipGetSymbolAddress((void**)&ctx->scratch_ptr, HIP_SYMBOL(scratch)) != hipSuccess ||
+      ctx->scratch_ptr == nullptr) {
     (void)hipGetLastError();
     rt_destroy(ctx);  // frees whatever was created before the failure
     return RT_ERR_DEVICE;
@@ -1492,6 +1551,23 @@ int rt_render_device(rt_ctx* ctx, const rt_render_params* p, float* d_rgb_sum, u
   if (rc != RT_OK) return rc;
   double* accum = nullptr;
   rc = render_into_accum(ctx, p, stats, &accum);
+  if (rc != RT_OK) return rc;
+  PassInfo ps{};
+  check_window(ctx, p->width, p->height, &p->window, ps);
+  uint64_t n = (uint64_t)ps.n_pixels * 3;
+  to_float_kernel<<<blocks_for(n), kBlock, 0, ctx->stream>>>(accum, d_rgb_sum, n);
+  RT_HIP(ctx, hipGetLastError());
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return RT_OK;
+}
+
+int rt_render_device_noalloc(rt_ctx* ctx, const rt_render_params* p, float* d_rgb_sum) {
+  if (!ctx) return RT_ERR_INVALID;
+  if (!d_rgb_sum) return fail(ctx, RT_ERR_INVALID, "null output");
+  int rc = output_on_device(ctx, d_rgb_sum);
+  if (rc != RT_OK) return rc;
+  double* accum = nullptr;
+  rc = render_into_accum(ctx, p, nullptr, &accum, true);
   if (rc != RT_OK) return rc;
   PassInfo ps{};
   check_window(ctx, p->width, p->height, &p->window, ps);

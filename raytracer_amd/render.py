@@ -79,6 +79,10 @@ class Context:
                                                       st.ctypes.data if timing else None))
         return st
 
+    def render_into_noalloc(self, p, device_ptr):
+        """render_into through the entry point that allocates nothing (fixed scratch array)."""
+        self._check(abi.device_lib().rt_render_device_noalloc(self._h, C.byref(p), C.c_void_p(device_ptr)))
+
     def first_hit(self, width, height, window=None):
         L = abi.device_lib()
         w = abi.Window(*window) if window is not None else abi.Window(0, 0, 0, 0)
