@@ -1469,9 +1469,11 @@ int oracle_camera_ray(const oracle_scene* o, const rt_render_params* p, uint32_t
   return RT_OK;
 }
 
-// Deterministic first-hit pass (pixel-centre pinhole rays, media skipped).
-int oracle_first_hit(const oracle_scene* o, uint32_t width, uint32_t height,
-                     const rt_window* window, uint32_t* id, double* t, double* normal) {
+// Deterministic first-hit pass (pixel-centre pinhole rays, media skipped), rows dealt out to
+// n_threads threads (each pixel is independent, so the thread count cannot change a result).
+int oracle_first_hit_mt(const oracle_scene* o, uint32_t width, uint32_t height,
+                        const rt_window* window, int n_threads, uint32_t* id, double* t,
+                        double* normal) {
   if (!o || !id || !t || !normal) return RT_ERR_INVALID;
   rt_render_params p{};
   p.width = width;
@@ -1480,20 +1482,31 @@ int oracle_first_hit(const oracle_scene* o, uint32_t width, uint32_t height,
   uint32_t x0, y0, w, h;
   window_of(p, x0, y0, w, h);
   if (x0 + w > width || y0 + h > height) return RT_ERR_INVALID;
-  HitCtx cx{nullptr, true, nullptr};
-  for (uint32_t row = 0; row < h; ++row)
-    for (uint32_t col = 0; col < w; ++col) {
-      uint32_t x = x0 + col, y = y0 + row;
-      double u = ((double)x + 0.5) / ((double)width - 1.0);
-      double v = ((double)(height - y) + 0.5) / ((double)height - 1.0);
-      Ray ray = o->d->camera.get_ray_pinhole(u, v);
-      OptHit hr = o->d->world->hit(ray, Range{0.001, INF}, cx);
-      size_t i = (size_t)row * w + col;
-      id[i] = hr.some ? hr.rec.object : 0xFFFFFFFFu;
-      t[i] = hr.some ? hr.rec.t : 0.0;
-      for (int k = 0; k < 3; ++k) normal[i * 3 + k] = hr.some ? hr.rec.normal[k] : 0.0;
-    }
+  std::atomic<uint32_t> next_row{0};
+  auto work = [&]() {
+    HitCtx cx{nullptr, true, nullptr};
+    for (uint32_t row = next_row.fetch_add(1); row < h; row = next_row.fetch_add(1))
+      for (uint32_t col = 0; col < w; ++col) {
+        uint32_t x = x0 + col, y = y0 + row;
+        double u = ((double)x + 0.5) / ((double)width - 1.0);
+        double v = ((double)(height - y) + 0.5) / ((double)height - 1.0);
+        Ray ray = o->d->camera.get_ray_pinhole(u, v);
+        OptHit hr = o->d->world->hit(ray, Range{0.001, INF}, cx);
+        size_t i = (size_t)row * w + col;
+        id[i] = hr.some ? hr.rec.object : 0xFFFFFFFFu;
+        t[i] = hr.some ? hr.rec.t : 0.0;
+        for (int k = 0; k < 3; ++k) normal[i * 3 + k] = hr.some ? hr.rec.normal[k] : 0.0;
+      }
+  };
+  std::vector<std::thread> pool;
+  for (int k = 1; k < n_threads; ++k) pool.emplace_back(work);
+  work();
+  for (std::thread& th : pool) th.join();
   return RT_OK;
+}
+int oracle_first_hit(const oracle_scene* o, uint32_t width, uint32_t height,
+                     const rt_window* window, uint32_t* id, double* t, double* normal) {
+  return oracle_first_hit_mt(o, width, height, window, 1, id, t, normal);
 }
 
 // mode 0: reference topology, recursive ray_color (the literal restatement)

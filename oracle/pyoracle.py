@@ -48,6 +48,7 @@ def lib():
     L.oracle_camera_ray.argtypes = [vp, C.POINTER(abi.RenderParams), C.c_uint32, C.c_uint32,
                                     C.c_uint32, d3, d3, d3]
     L.oracle_first_hit.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(abi.Window), vp, vp, vp]
+    L.oracle_first_hit_mt.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(abi.Window), C.c_int, vp, vp, vp]
     L.oracle_render.argtypes = [vp, C.POINTER(abi.RenderParams), C.c_int, vp, C.c_uint32, vp,
                                 C.c_uint32, C.c_int, vp, vp]
     L.oracle_ranks.argtypes = [vp, vp, C.c_uint32]
@@ -148,14 +149,14 @@ class Oracle:
                                        C.cast(C.byref(t), C.POINTER(C.c_double))), "camera_ray")
         return list(o), list(d), t.value
 
-    def first_hit(self, width, height, window=None):
+    def first_hit(self, width, height, window=None, threads=1):
         w = abi.Window(*window) if window is not None else abi.Window(0, 0, 0, 0)
         hh, ww = (height, width) if window is None else (window[3], window[2])
         ids = np.empty((hh, ww), dtype=np.uint32)
         t = np.empty((hh, ww), dtype=np.float64)
         n = np.empty((hh, ww, 3), dtype=np.float64)
-        _check(lib().oracle_first_hit(self._h, width, height, C.byref(w), ids.ctypes.data,
-                                      t.ctypes.data, n.ctypes.data), "first_hit")
+        _check(lib().oracle_first_hit_mt(self._h, width, height, C.byref(w), threads, ids.ctypes.data,
+                                         t.ctypes.data, n.ctypes.data), "first_hit")
         return ids, t, n
 
     def render(self, params, mode=MODE_REFERENCE, bvh=None, threads=1, stats=False):
