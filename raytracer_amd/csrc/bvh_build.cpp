@@ -609,6 +609,8 @@ std::string flatten_scene(const rt_scene& s, FlatScene& out, int& code) {
     d.needs_uv = textured ? tex_needs_uv[m.texture] : 0;
     d.textured = textured && s.textures[m.texture].kind != RT_TEX_SOLID ? 1u : 0u;
     if (textured && !d.textured) std::memcpy(d.albedo, s.textures[m.texture].color, sizeof d.albedo);
+    // (a Dielectric has no albedo: the slot carries 1 / index_of_refraction, dielectric.rs:16-20)
+    if (m.kind == RT_MAT_DIELECTRIC) d.albedo[0] = 1.0 / m.param;
     out.materials[i] = d;
   }
   out.perlin.assign(s.perlin, s.perlin + s.n_perlin);
@@ -679,6 +681,7 @@ std::string flatten_scene(const rt_scene& s, FlatScene& out, int& code) {
       d.p[1] = p.center[1];
       d.p[2] = p.center[2];
       d.p[3] = p.radius;
+      d.p[4] = 1.0 / p.radius;  // the reciprocal `(p - center) / radius` multiplies by (vec3.rs:214-219)
     } else if (p.kind == RT_PRIM_MOVING_SPHERE) {
       d.kind = DP_MOVING_SPHERE;
       d.p[0] = p.center[0];

@@ -109,10 +109,28 @@ struct PassInfo {
   uint32_t sample_base;        // absolute index of the pass's first sample
   uint32_t first_pass;         // 1: resolve starts the sums
   uint32_t samples;            // samples per pixel in this pass
+  uint32_t tiled;              // window pixels are numbered 8x8 tile by tile (by_ww divides by tiles per row)
   uint64_t seed;
 };
 
 RT_DEV uint32_t lane_id() { return __lane_id(); }
+
+// Pixel of the window's `local`-th path slot.  Which pixel a slot names changes no result (draws
+// are addressed by pixel and sample): windows that divide into 8x8 tiles are numbered tile by
+// tile, so that the 64 camera rays of a wave cover a square instead of a 64-pixel row segment
+// and stay together longer in the hierarchy.
+RT_DEV void pixel_of(const PassInfo& ps, uint32_t local, uint32_t& x, uint32_t& y) {
+  if (ps.tiled) {
+    const uint32_t tile = local >> 6, in = local & 63u;
+    const uint32_t ty = fastdiv(tile, ps.by_ww), tx = tile - ty * (ps.ww >> 3);
+    x = ps.x0 + (tx << 3) + (in & 7u);
+    y = ps.y0 + (ty << 3) + (in >> 3);
+  } else {
+    const uint32_t row = fastdiv(local, ps.by_ww);
+    x = ps.x0 + (local - row * ps.ww);
+    y = ps.y0 + row;
+  }
+}
 
 // Where workgroup `block` appends the paths that live on after `bounce`.
 RT_DEV uint32_t* next_live_counter(const PathBuffers& pb, uint32_t bounce, uint32_t block) {
@@ -230,8 +248,8 @@ raygen_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps) {
   uint32_t path = blockIdx.x * kBlock + threadIdx.x;
   if (path >= ps.n_paths) return;
   uint32_t s_local = fastdiv(path, ps.by_pixels), local = path - s_local * ps.n_pixels;
-  uint32_t row = fastdiv(local, ps.by_ww);
-  uint32_t x = ps.x0 + (local - row * ps.ww), y = ps.y0 + row;
+  uint32_t x, y;
+  pixel_of(ps, local, x, y);
   DrawKey key{ps.seed, y * ps.width + x, ps.sample_base + s_local, 0u};
   V3 origin, dir;
   double time;
@@ -273,8 +291,8 @@ extend_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32
       double4 ro = pb.ray_o[path];
       double4 rdv = pb.ray_d[path];
       uint32_t s_local = fastdiv(path, ps.by_pixels), local = path - s_local * ps.n_pixels;
-      uint32_t row = fastdiv(local, ps.by_ww);
-      uint32_t x = ps.x0 + (local - row * ps.ww), y = ps.y0 + row;
+      uint32_t x, y;
+      pixel_of(ps, local, x, y);
       DrawKey key{ps.seed, y * ps.width + x, ps.sample_base + s_local, bounce};
       stat<STATS>(st, RT_STAT_RAYS);
       Closest h = closest_hit<STATS, MEDIA, MEDIA, OVERFLOW>(sc, lds, v3(ro.x, ro.y, ro.z), v3(rdv.x, rdv.y, rdv.z),
@@ -374,7 +392,7 @@ RT_DEV ShadeOut shade_begin(const DeviceScene& sc, uint32_t kind, const DPrim& p
     }
     out.attenuation = v3(m.albedo);
   } else if (kind == RT_MAT_DIELECTRIC) {  // dielectric.rs:14-38
-    double ratio = rec.front ? 1.0 / m.param : m.param;
+    double ratio = rec.front ? m.albedo[0] : m.param;  // albedo[0] of a Dielectric: 1.0 / param
     double cos_theta = fmin(vdot(vneg(ud), rec.normal), 1.0);
     double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
     bool cannot_refract = ratio * sin_theta > 1.0;
@@ -460,8 +478,8 @@ shade_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps, uint32_t bounce, uint3
         double4 rdv = pb.ray_d[path];
         const DPrim pr = sc.prims[pb.hit_item[path]];
         uint32_t s_local = fastdiv(path, ps.by_pixels), local = path - s_local * ps.n_pixels;
-        uint32_t row = fastdiv(local, ps.by_ww);
-        uint32_t x = ps.x0 + (local - row * ps.ww), y = ps.y0 + row;
+        uint32_t x, y;
+        pixel_of(ps, local, x, y);
         key.pixel = y * ps.width + x;
         key.sample = ps.sample_base + s_local;
         const uint32_t kind = BIN == kAnyBin ? (pr.kind >> 8) & 7u : (uint32_t)BIN - 1u;
@@ -605,8 +623,8 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
       so.needs_vector = false;
       if (valid) {
         uint32_t s_local = fastdiv(path, ps.by_pixels), local = path - s_local * ps.n_pixels;
-        uint32_t row = fastdiv(local, ps.by_ww);
-        uint32_t x = ps.x0 + (local - row * ps.ww), y = ps.y0 + row;
+        uint32_t x, y;
+        pixel_of(ps, local, x, y);
         key.pixel = y * ps.width + x;
         key.sample = ps.sample_base + s_local;
         V3 o, d;
@@ -743,6 +761,9 @@ __global__ void __launch_bounds__(kBlock)
 resolve_kernel(PathBuffers pb, PassInfo ps, double* accum) {
   uint32_t pixel = blockIdx.x * kBlock + threadIdx.x;
   if (pixel >= ps.n_pixels) return;
+  uint32_t x, y;
+  pixel_of(ps, pixel, x, y);
+  const uint32_t out = (y - ps.y0) * ps.ww + (x - ps.x0);  // the sums are row-major
   double r, g, b;
   uint32_t s = 0;
   if (ps.first_pass) {  // Iterator::sum = reduce(a + b): starts from the first sample
@@ -752,9 +773,9 @@ resolve_kernel(PathBuffers pb, PassInfo ps, double* accum) {
     b = L.z;
     s = 1;
   } else {
-    r = accum[3 * (size_t)pixel + 0];
-    g = accum[3 * (size_t)pixel + 1];
-    b = accum[3 * (size_t)pixel + 2];
+    r = accum[3 * (size_t)out + 0];
+    g = accum[3 * (size_t)out + 1];
+    b = accum[3 * (size_t)out + 2];
   }
   for (; s < ps.samples; ++s) {
     double4 L = pb.radiance[(size_t)s * ps.n_pixels + pixel];
@@ -762,9 +783,9 @@ resolve_kernel(PathBuffers pb, PassInfo ps, double* accum) {
     g = g + L.y;
     b = b + L.z;
   }
-  accum[3 * (size_t)pixel + 0] = r;
-  accum[3 * (size_t)pixel + 1] = g;
-  accum[3 * (size_t)pixel + 2] = b;
+  accum[3 * (size_t)out + 0] = r;
+  accum[3 * (size_t)out + 1] = g;
+  accum[3 * (size_t)out + 2] = b;
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -792,8 +813,9 @@ first_hit_kernel(DeviceScene sc, LdsLayout lay, PassInfo ps, uint32_t* id, doubl
 template <bool CHAINS, bool OVERFLOW>
 RT_DEV void first_hit_pixel(const DeviceScene& sc, const LdsScene& lds, const PassInfo& ps,
                             uint32_t local, uint32_t* id, double* t_out, double* normal) {
-  uint32_t row = fastdiv(local, ps.by_ww);
-  uint32_t x = ps.x0 + (local - row * ps.ww), y = ps.y0 + row;
+  uint32_t x, y;
+  pixel_of(ps, local, x, y);
+  const size_t out = (size_t)(y - ps.y0) * ps.ww + (x - ps.x0);  // the outputs are row-major
   double u = ((double)x + 0.5) / ((double)ps.width - 1.0);
   double v = ((double)(ps.height - y) + 0.5) / ((double)ps.height - 1.0);
   const rt_camera& c = sc.cam;
@@ -807,20 +829,20 @@ RT_DEV void first_hit_pixel(const DeviceScene& sc, const LdsScene& lds, const Pa
   Stats st;
   Closest h = closest_hit<false, false, CHAINS, OVERFLOW>(sc, lds, origin, dir, c.time0, 0.001, key, st);
   if (h.item == kNoPrim) {
-    id[local] = 0xFFFFFFFFu;
-    t_out[local] = 0.0;
-    normal[3 * (size_t)local + 0] = 0.0;
-    normal[3 * (size_t)local + 1] = 0.0;
-    normal[3 * (size_t)local + 2] = 0.0;
+    id[out] = 0xFFFFFFFFu;
+    t_out[out] = 0.0;
+    normal[3 * out + 0] = 0.0;
+    normal[3 * out + 1] = 0.0;
+    normal[3 * out + 2] = 0.0;
     return;
   }
   const DPrim pr = sc.prims[h.item];
   Record rec = make_record(sc, pr, origin, dir, c.time0, h.t, false);
-  id[local] = pr.object;
-  t_out[local] = h.t;
-  normal[3 * (size_t)local + 0] = rec.normal.x;
-  normal[3 * (size_t)local + 1] = rec.normal.y;
-  normal[3 * (size_t)local + 2] = rec.normal.z;
+  id[out] = pr.object;
+  t_out[out] = h.t;
+  normal[3 * out + 0] = rec.normal.x;
+  normal[3 * out + 1] = rec.normal.y;
+  normal[3 * out + 2] = rec.normal.z;
 }
 
 // ----------------------------------------------------------------- host
@@ -1025,7 +1047,10 @@ int check_window(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_window* 
   }
   ps.n_pixels = ps.ww * ps.wh;
   ps.by_pixels = make_fastdiv(ps.n_pixels);
-  ps.by_ww = make_fastdiv(ps.ww);
+  const char* tiles_env = getenv("MI355RT_TILES");  // 0: row-major numbering (A/B timing)
+  const bool tiles_off = tiles_env && atoi(tiles_env) == 0;
+  ps.tiled = (!tiles_off && ps.ww % 8u == 0 && ps.wh % 8u == 0) ? 1u : 0u;
+  ps.by_ww = make_fastdiv(ps.tiled ? ps.ww / 8u : ps.ww);
   // the two divisors are checked on the values where a wrong multiplier would show first
   for (const FastDiv* f : {&ps.by_pixels, &ps.by_ww})
     for (uint64_t k : {(uint64_t)1, (uint64_t)2, (uint64_t)3, (uint64_t)(0xFFFFFFFFu / f->d)})

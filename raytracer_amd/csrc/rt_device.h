@@ -390,7 +390,8 @@ RT_DEV Record make_record(const DeviceScene& sc, const DPrim& pr, V3 o, V3 d, do
   } else {  // sphere.rs:52-63
     V3 c = kind == DP_SPHERE ? v3(pr.p[0], pr.p[1], pr.p[2]) : moving_center(sc, pr, time);
     r.p = vadd(lo, vscale(ld, t));
-    V3 outward = vdiv(vsub(r.p, c), pr.p[3]);
+    // (p - center) / radius = (p - center) * radius.recip(); a sphere's record carries the reciprocal
+    V3 outward = kind == DP_SPHERE ? vscale(vsub(r.p, c), pr.p[4]) : vdiv(vsub(r.p, c), pr.p[3]);
     if (want_uv) sphere_uv(outward, r.u, r.v);
     set_face_normal(r, ld, outward);
   }
@@ -537,6 +538,18 @@ RT_DEV V3 wave_rand_in_unit_sphere(bool need, const DrawKey& key, lds_u32* xch, 
     const uint32_t n = (uint32_t)__popcll(pending);
     const uint32_t c_log = n == 1u ? 6u : (uint32_t)__clz((int)(n - 1u)) - 26u;
     const bool mine = (pending >> lane) & 1ull;
+    if (c_log == 0u) {
+      // more than half of the wave is looking: no helper to share, each lane tries its own next
+      // candidate and nothing is exchanged
+      double x, y, z;
+      sym3_42(draw_block(key.seed, key.pixel, key.sample, key.bounce, DRAW_SCATTER, tried), x, y, z);
+      const bool got = mine && tried < kMaxRejections &&
+                       (x * x + y * y + z * z < 1.0 || tried == kMaxRejections - 1u);
+      if (got) v = v3(x, y, z);
+      pending &= ~__ballot(got);
+      tried += 1u;
+      continue;
+    }
     const uint32_t rank = (uint32_t)__popcll(pending & ((1ull << lane) - 1ull));
     if (mine) {
       xch[rank] = key.pixel;
