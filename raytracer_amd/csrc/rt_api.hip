@@ -62,6 +62,14 @@ const uint32_t kBins = 1 + RT_MAT_KINDS;  // miss + one per material kind
 const uint32_t kSubQueues = 8;
 const uint32_t kCounterStride = 32 * (1 + kSubQueues);
 const int kAnyBin = 7;                    // shade_kernel over the deferred queue: any material kind
+// [kWorkWord] of a bounce's row: how many of its live paths the waves of its trace launch have drawn
+const uint32_t kWorkWord = 16;
+#ifndef RT_TRIPS_PER_GRAB
+#define RT_TRIPS_PER_GRAB 4
+#endif
+#ifndef RT_RUN_INTERLEAVE_LOG
+#define RT_RUN_INTERLEAVE_LOG 0
+#endif
 
 struct PathBuffers {
   double4* ray_o;     // origin xyz, time
@@ -598,19 +606,47 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
   uint32_t n_staged = 0, n_deferred = 0;  // wave-uniform
   Stats st;
   if (STATS) st.clear();
+  // A wave's 64 rays per trip.  Which trips a wave runs is settled as it goes: the waves of a
+  // launch draw runs of kTripsPerGrab trips from one counter, so that all of them stay busy
+  // until the queue is empty whatever their rays cost (with a fixed stride the chip spent the
+  // end of every launch waiting for its slowest workgroups).  The tail variant keeps the fixed
+  // stride: its paths are few.  The queue entry of the next trip is fetched a trip ahead, so a
+  // trip starts with one round trip to memory (the ray); a run is drawn where the last one ends
+  // (drawn a trip ahead, the returned value is one more register alive across the whole trip,
+  // which measured slower).
+  constexpr uint32_t kTripsPerGrab = RT_TRIPS_PER_GRAB;
+  // Run number r covers trips ((r >> L) * kTripsPerGrab + j) << L | (r & (2^L - 1)), j = 0 .. kTripsPerGrab - 1:
+  // with L > 0 the runs drawn at about the same time interleave trip by trip instead of each
+  // covering a stretch of the queue of its own.
+  constexpr uint32_t kRunLog = RT_RUN_INTERLEAVE_LOG;
+  uint32_t* const work = counters + kWorkWord;
   const uint32_t stride = gridDim.x * (uint32_t)BLOCK;
-  // a wave's 64 rays per trip; the trip count differs between the waves of a workgroup.
-  // The queue entry of the next trip is fetched a trip ahead, so that a trip starts with
-  // one round trip to memory (the ray) instead of two.
-  const uint32_t first_i = blockIdx.x * (uint32_t)BLOCK + threadIdx.x;
-  uint32_t path_ahead = FIRST ? first_i : first_i < n_live ? live.path(first_i) : 0u;
-  for (uint32_t base = blockIdx.x * (uint32_t)BLOCK + (threadIdx.x & ~63u); base < n_live;
-       base += stride) {
+  auto draw_run = [&]() -> uint32_t {  // index of the first ray of the run's first trip
+    uint32_t v = 0;
+    if (lane_id() == 0) v = atomicAdd(work, 1u);
+    const uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+    return ((((r >> kRunLog) * kTripsPerGrab) << kRunLog) + (r & ((1u << kRunLog) - 1u))) * 64u;
+  };
+  constexpr uint32_t kTripStep = 64u << kRunLog;  // from one trip of a run to its next
+  uint32_t base = TAIL ? blockIdx.x * (uint32_t)BLOCK + (threadIdx.x & ~63u) : draw_run();
+  uint32_t trip_in_run = 0;
+  uint32_t path_ahead = 0;
+  {
+    const uint32_t first_i = base + (threadIdx.x & 63u);
+    path_ahead = FIRST ? first_i : first_i < n_live ? live.path(first_i) : 0u;
+  }
+  while (base < n_live) {
     const uint32_t i = base + (threadIdx.x & 63u);
     bool valid = i < n_live;
     uint32_t path = path_ahead;
-    if (FIRST) path_ahead = i + stride;
-    else if (i + stride < n_live && i + stride > i) path_ahead = live.path(i + stride);
+    // where the next trip starts, when that is known already
+    uint32_t next_base = TAIL ? base + stride : base + kTripStep, next_trip = trip_in_run + 1u;
+    const bool draws = !TAIL && (next_trip == kTripsPerGrab || next_base >= n_live);
+    if (!draws) {
+      const uint32_t ni = next_base + (threadIdx.x & 63u);
+      if (FIRST) path_ahead = ni;
+      else if (ni < n_live && next_base > base) path_ahead = live.path(ni);
+    }
     uint32_t bounce = first_bounce;
     bool survives, deferred = false;
     do {
@@ -642,7 +678,24 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
         stat<STATS>(st, RT_STAT_RAYS);
         RT_LP(st, LP_RAY);
         RT_TICK(st, LP_T_SETUP, tick);
+#if defined(RT_DBG_NO_TRAVERSE)
+        Closest h;
+        if (MODE == kTraceBounce) {
+          h.item = path % 488u;
+          h.t = 1.0;
+          h.kind = sc.prims[h.item].kind;
+        } else {
+          h = closest_hit<STATS, MEDIA, MEDIA, OVERFLOW>(sc, lds, o, d, time, 0.001, key, st);
+        }
+#else
         Closest h = closest_hit<STATS, MEDIA, MEDIA, OVERFLOW>(sc, lds, o, d, time, 0.001, key, st);
+#endif
+#if defined(RT_DBG_NO_SHADE)
+        if (MODE == kTraceBounce) {
+          if (h.item != kNoPrim && h.t == 12345.0) pb.radiance[path] = make_double4(h.t, 0.0, 0.0, 0.0);
+          h.item = kNoPrim;
+        }
+#endif
         RT_TICK(st, LP_T_TRAVERSE, tick);
         // ... and starts from beta = 1, L = 0
         V3 beta = v3(1.0, 1.0, 1.0);
@@ -701,8 +754,14 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
       RT_TICK(st, LP_T_SHADE, tick);
       {  // whole waves: the lanes look for their random vectors together
         // (the wave's part of the first two stack rows is idle between traversals)
+#if defined(RT_DBG_NO_VECTOR)
+        V3 inside = MODE == kTraceBounce ? v3(0.3, 0.4, 0.5)
+                                         : wave_rand_in_unit_sphere(survives && so.needs_vector, key,
+                                                                    lds.stack - (threadIdx.x & 63u), BLOCK, st);
+#else
         V3 inside = wave_rand_in_unit_sphere(survives && so.needs_vector, key,
                                              lds.stack - (threadIdx.x & 63u), BLOCK, st);
+#endif
         RT_TICK(st, LP_T_VECTOR, tick);
         shade_finish(so, inside);
       }
@@ -737,6 +796,16 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
         }
       }
     }
+    if (draws) {
+      next_base = draw_run();
+      next_trip = 0;
+      const uint32_t ni = next_base + (threadIdx.x & 63u);
+      if (FIRST) path_ahead = ni;
+      else if (ni < n_live) path_ahead = live.path(ni);
+    }
+    if (TAIL && next_base <= base) break;  // (32-bit wrap at the very end of the index range)
+    base = next_base;
+    trip_in_run = next_trip;
   }
   if (!TAIL && n_staged) wave_flush(stage, n_staged, next_count, next_live);
   if (DEFER && n_deferred) wave_flush(defer_stage, n_deferred, counters + kAnyBin, pb.bins);
@@ -1509,7 +1578,9 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* scene) {
       return fail(ctx, RT_ERR_INVALID, "MI355RT_TRACE_BLOCK must be 256 or 512");
     ctx->trace_block = tb;
     const uint32_t per_cu = ctx->general ? (tb == 256u ? 3u : 1u) : 1024u / tb;  // resident
-    ctx->trace_blocks_per_cu = 4096u / tb;  // launched: the grid drains more evenly in smaller pieces
+    // launched: as many workgroups as are resident together; the waves draw their work from a
+    // counter, so nothing is gained by more
+    ctx->trace_blocks_per_cu = per_cu;
     if (const char* e = getenv("MI355RT_TRACE_BLOCKS_PER_CU"))
       ctx->trace_blocks_per_cu = std::max(1u, (uint32_t)strtoul(e, nullptr, 10));
     // LDS of a CU split between the resident workgroups, minus the per-wave queue stages

@@ -20,6 +20,7 @@ keys = [k for k, _ in sweeps]
 values = [v.split(",") for _, v in sweeps]
 scene = HostScene.load_frozen(os.path.join(ROOT, "tests", "golden", name + ".rtscene"))
 scene.set_image(w, h)
+depth = int(os.environ.get('SWEEP_DEPTH', scene.max_depth))
 ref = None
 for combo in itertools.product(*values) if values else [()]:
     flags = 0
@@ -34,7 +35,7 @@ for combo in itertools.product(*values) if values else [()]:
     ctx.upload(scene)
     best = 1e9
     for rep in range(3):
-        p = ctx.params(w, h, 0, spp, scene.max_depth, seed=1, flags=flags)
+        p = ctx.params(w, h, 0, spp, depth, seed=1, flags=flags)
         t0 = time.perf_counter()
         img, st = ctx.render(p, dtype=np.float32, timing=True)
         best = min(best, time.perf_counter() - t0)

@@ -17,6 +17,7 @@ scene = HostScene.load_frozen(os.path.join(ROOT, "tests", "golden", name + ".rts
 scene.set_image(w, h)
 ctx = Context(0)
 ctx.upload(scene)
-img = ctx.render(ctx.params(w, h, 0, spp, scene.max_depth, seed=1), dtype=np.float32)
+depth = int(os.environ.get('SWEEP_DEPTH', scene.max_depth))
+img = ctx.render(ctx.params(w, h, 0, spp, depth, seed=1), dtype=np.float32)
 print(name, w, h, spp, "mean", float(img.mean()) / spp)
 ctx.close()
