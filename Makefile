@@ -40,10 +40,18 @@ $(LIBDIR)/raytracer: raytracer_amd/host/main.cpp $(LIBDIR)/libmi355rt_host.so $(
 	$(CXX) $(CXXFLAGS) -o $@ raytracer_amd/host/main.cpp -L$(LIBDIR) -lmi355rt_host -lmi355rt \
 	    -Wl,-rpath,'$$ORIGIN'
 
+# Device listing of the render path and the check that no vector-register spill sits ahead of
+# the EXEC restore of its block (tools/check_spills.py says what that breaks).
+$(LIBDIR)/rt_api.s: $(DEV_SRC) $(DEV_HDR)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -S --cuda-device-only -o $@ raytracer_amd/csrc/rt_api.hip
+spillcheck: $(LIBDIR)/rt_api.s
+	python3 tools/check_spills.py $(LIBDIR)/rt_api.s
+
 clean:
 	rm -rf $(LIBDIR) oracle/liboracle.so oracle/_ref
 
-.PHONY: all host device cli oracle clean
+.PHONY: all host device cli oracle clean spillcheck
 
 # development build with loop-trip counters (tools/lane_profile.py); not shipped
 laneprof:

@@ -240,9 +240,17 @@ int rt_host_human_duration(uint64_t millis, char* buf, size_t buf_len);
 typedef struct rt_ctx rt_ctx;
 
 typedef struct rt_config {
-  int32_t device;            /* HIP device ordinal */
-  uint32_t reserved;
-  uint64_t max_paths_in_flight; /* 0 = default; bounds device memory for path state */
+  int32_t device;            /* HIP device ordinal (n_devices <= 1 and devices == NULL) */
+  uint32_t n_devices;        /* > 1: a device group, see below; 0 or 1: one device */
+  uint64_t max_paths_in_flight; /* 0 = default; bounds device memory for path state, per device */
+  /* Device group: the HIP ordinals of its members; devices[0] is the root.  The context then
+   * renders with all of them: rt_upload_scene copies the scene to each, rt_render and
+   * rt_render_device give member k of N the samples [begin + n k / N, begin + n (k + 1) / N) of every
+   * pixel (the pixel-sample space of src/main.rs:87-97 shards by sample range) and add the
+   * float shares onto the root with one reduce(sum) over RCCL communicators the context owns
+   * (ncclCommInitAll in this process).  rt_render_device's buffer lives on the root's device.
+   * rt_first_hit runs on the root; rt_render_f64 and rt_render_device_noalloc are not for groups. */
+  const int32_t* devices;
 } rt_config;
 
 typedef struct rt_window { /* sub-rectangle of the image; w==0 means the whole image */

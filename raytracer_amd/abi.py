@@ -112,8 +112,8 @@ class HostOptions(C.Structure):
 
 
 class Config(C.Structure):
-    _fields_ = [("device", C.c_int32), ("reserved", C.c_uint32),
-                ("max_paths_in_flight", C.c_uint64)]
+    _fields_ = [("device", C.c_int32), ("n_devices", C.c_uint32),
+                ("max_paths_in_flight", C.c_uint64), ("devices", C.POINTER(C.c_int32))]
 
 
 class Window(C.Structure):

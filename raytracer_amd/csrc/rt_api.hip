@@ -36,6 +36,9 @@
 #include <new>
 #include <string>
 #include <limits>
+#include <memory>
+#include <thread>
+#include <dlfcn.h>
 #include <type_traits>
 #include <vector>
 
@@ -273,7 +276,7 @@ raygen_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps) {
 #define RT_EXTEND_MEDIA_WAVES 3
 #endif
 template <bool STATS, bool MEDIA, bool OVERFLOW>
-__global__ void __launch_bounds__(kBlock, MEDIA ? RT_EXTEND_MEDIA_WAVES : 4)  // waves per SIMD to fit registers for
+__global__ void __launch_bounds__(kBlock, STATS ? 1 : MEDIA ? RT_EXTEND_MEDIA_WAVES : 4)  // waves per SIMD to fit registers for
 extend_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_t bounce,
               unsigned long long* g_stats) {
   extern __shared__ __align__(16) char smem[];
@@ -584,8 +587,13 @@ RT_DEV void wave_flush(const uint32_t* stage, uint32_t n, uint32_t* g_counter, u
 // carry the camera block in scalar registers: that pressure showed as scalar spills all
 // through the per-trip code).
 enum { kTraceBounce = 0, kTraceTail = 1, kTraceFirst = 2 };
+// Waves per SIMD the register allocation is made for.  The instrumented (STATS) variants carry
+// two dozen counters per lane and are not timed: they get registers enough not to spill at all.
+constexpr int trace_waves_per_simd(int block, bool stats, bool media) {
+  return stats ? (block >= 512 ? 2 : 1) : media ? RT_TRACE_MEDIA_WAVES : 4;
+}
 template <int BLOCK, bool STATS, bool MEDIA, bool OVERFLOW, int MODE>
-__global__ void __launch_bounds__(BLOCK, MEDIA ? RT_TRACE_MEDIA_WAVES : 4)  // waves per SIMD to fit registers for
+__global__ void __launch_bounds__(BLOCK, trace_waves_per_simd(BLOCK, STATS, MEDIA))
 trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_t first_bounce_arg,
              uint32_t max_depth, unsigned long long* g_stats) {
   constexpr bool TAIL = MODE == kTraceTail, FIRST = MODE == kTraceFirst;
@@ -940,7 +948,9 @@ struct rt_ctx {
   uint64_t max_paths = 0;
   uint32_t n_cus = 0;
   bool have_scene = false;
-  FlatScene flat;     // host copy (BVH inspection)
+  // host copy of what was uploaded; the contexts of a device group share one
+  std::shared_ptr<const FlatScene> flat_ptr = std::make_shared<FlatScene>();
+  const FlatScene& flat() const { return *flat_ptr; }
   DeviceScene ds{};
   LdsLayout lds{};
   DeviceArray<float4> nodes;
@@ -974,6 +984,13 @@ struct rt_ctx {
   std::vector<hipEvent_t> events;  // RT_FLAG_TIMING: three per bounce (before extend, between, after shade)
   DeviceArray<unsigned char> staging;     // device side of host-buffer results (rt_render, rt_first_hit)
   unsigned char* scratch_ptr = nullptr;  // this device's copy of `scratch` (rt_render_device_noalloc)
+  // Device group (rt_config.n_devices > 1): this context is the root (devices[0]) and owns one
+  // context per further device, a float buffer per member for its share of the samples, and
+  // the RCCL communicators the shares are reduced over (none: the shares are added through host memory).
+  std::vector<rt_ctx*> peers;
+  DeviceArray<float> share;
+  void* rccl = nullptr;                // dlopen handle of librccl
+  std::vector<void*> comms;            // ncclComm_t per member, root first
 };
 
 namespace {
@@ -1295,16 +1312,16 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats, d
     return fail(ctx, RT_ERR_LIMIT, "window has more pixels than max_paths_in_flight");
 
   // the MEDIA kernels carry the rare cases: constant media and records tied to the reference's box chain
-  const bool media = ctx->flat.has_media || !ctx->flat.chain_ranges.empty();
+  const bool media = ctx->flat().has_media || !ctx->flat().chain_ranges.empty();
   const bool solid = ctx->solid;
   // traversal and scatter run fused, with the hits on procedural or image textures deferred
   // to a shade kernel of their own; RT_FLAG_BINNED forces the extend / shade-per-material pipeline
   const bool fused = !(p->flags & RT_FLAG_BINNED);
-  const bool defer = fused && ctx->flat.defers;
+  const bool defer = fused && ctx->flat().defers;
   const bool general = ctx->general;
   const uint32_t queues = fused ? (defer ? 1u : 0u) : kBins;
   uint32_t bins_present = 1u;
-  for (const DMaterial& m : ctx->flat.materials) bins_present |= 2u << m.kind;
+  for (const DMaterial& m : ctx->flat().materials) bins_present |= 2u << m.kind;
 
   PathBuffers scratch_pb{};
   double* accum = nullptr;
@@ -1431,12 +1448,12 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats, d
 
 extern "C" {
 
-int rt_create(const rt_config* cfg, rt_ctx** out) {
+static int create_single(int device, uint64_t max_paths_in_flight, rt_ctx** out) {
   if (!out) return RT_ERR_INVALID;
   *out = nullptr;
   rt_ctx* ctx = new (std::nothrow) rt_ctx();
   if (!ctx) return RT_ERR_NOMEM;
-  ctx->device = cfg ? cfg->device : 0;
+  ctx->device = device;
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
   if (e != hipSuccess || count <= 0 || ctx->device < 0 || ctx->device >= count) {
@@ -1457,8 +1474,8 @@ int rt_create(const rt_config* cfg, rt_ctx** out) {
     return RT_ERR_DEVICE;
   }
   ctx->n_cus = (uint32_t)prop.multiProcessorCount;
-  if (cfg && cfg->max_paths_in_flight) {
-    ctx->max_paths = cfg->max_paths_in_flight;
+  if (max_paths_in_flight) {
+    ctx->max_paths = max_paths_in_flight;
   } else if (const char* e = getenv("MI355RT_MAX_PATHS")) {
     ctx->max_paths = std::max<uint64_t>(strtoull(e, nullptr, 10), 1u << 16);
   } else {
@@ -1478,6 +1495,78 @@ int rt_create(const rt_config* cfg, rt_ctx** out) {
   return RT_OK;
 }
 
+
+// RCCL is looked up at run time, and only for device groups: a single-GPU caller never loads it.
+namespace {
+struct Rccl {
+  int (*CommInitAll)(void**, int, const int*) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*Reduce)(const void*, void*, size_t, int, int, int, void*, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+const int kNcclFloat = 7, kNcclSum = 0;  // ncclFloat32, ncclSum (rccl.h)
+bool load_rccl(void* lib, Rccl& r) {
+  r.CommInitAll = (decltype(r.CommInitAll))dlsym(lib, "ncclCommInitAll");
+  r.CommDestroy = (decltype(r.CommDestroy))dlsym(lib, "ncclCommDestroy");
+  r.Reduce = (decltype(r.Reduce))dlsym(lib, "ncclReduce");
+  r.GroupStart = (decltype(r.GroupStart))dlsym(lib, "ncclGroupStart");
+  r.GroupEnd = (decltype(r.GroupEnd))dlsym(lib, "ncclGroupEnd");
+  r.GetErrorString = (decltype(r.GetErrorString))dlsym(lib, "ncclGetErrorString");
+  return r.CommInitAll && r.CommDestroy && r.Reduce && r.GroupStart && r.GroupEnd && r.GetErrorString;
+}
+}  // namespace
+
+int rt_create(const rt_config* cfg, rt_ctx** out) {
+  if (!out) return RT_ERR_INVALID;
+  *out = nullptr;
+  const uint32_t n = cfg ? cfg->n_devices : 0u;
+  if (n > 1 && !cfg->devices) return RT_ERR_INVALID;
+  const uint64_t max_paths = cfg ? cfg->max_paths_in_flight : 0;
+  rt_ctx* root = nullptr;
+  int rc = create_single(n > 1 ? cfg->devices[0] : n == 1 && cfg->devices ? cfg->devices[0] : cfg ? cfg->device : 0,
+                         max_paths, &root);
+  if (rc != RT_OK || n <= 1) {
+    *out = root;
+    return rc;
+  }
+  bool distinct = true;
+  for (uint32_t k = 1; k < n; ++k) {
+    rt_ctx* peer = nullptr;
+    rc = create_single(cfg->devices[k], max_paths, &peer);
+    if (rc != RT_OK) {
+      rt_destroy(root);
+      return rc;
+    }
+    root->peers.push_back(peer);
+    for (uint32_t j = 0; j < k; ++j) distinct = distinct && cfg->devices[j] != cfg->devices[k];
+  }
+  // One communicator per member, made in this one process (ncclCommInitAll).  A group that names
+  // a device twice (two shares on one GPU: a rehearsal on a single-GPU machine) cannot have
+  // one, nor can a machine without librccl: such groups add their shares through host memory.
+  const char* staged = getenv("MI355RT_STAGED_REDUCE");
+  if (distinct && !(staged && atoi(staged))) {
+    root->rccl = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!root->rccl) root->rccl = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    Rccl r;
+    if (root->rccl && load_rccl(root->rccl, r)) {
+      root->comms.assign(n, nullptr);
+      int nrc = r.CommInitAll(root->comms.data(), (int)n, cfg->devices);
+      if (nrc != 0) {
+        root->error = std::string("ncclCommInitAll: ") + r.GetErrorString(nrc);
+        root->comms.clear();
+        rt_destroy(root);
+        return RT_ERR_DEVICE;
+      }
+    }
+  }
+  *out = root;
+  return RT_OK;
+}
+
+static int upload_flat(rt_ctx* ctx);
+
 int rt_upload_scene(rt_ctx* ctx, const rt_scene* scene) {
   if (!ctx) return RT_ERR_INVALID;
   if (!scene) return fail(ctx, RT_ERR_INVALID, "null scene");
@@ -1486,12 +1575,29 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* scene) {
   int code = RT_OK;
   std::string err;
   try {
-    err = flatten_scene(*scene, ctx->flat, code);
+    auto flat = std::make_shared<FlatScene>();
+    err = flatten_scene(*scene, *flat, code);
+    if (err.empty()) ctx->flat_ptr = flat;
   } catch (const std::exception& e) {
     return fail(ctx, RT_ERR_NOMEM, e.what());
   }
   if (!err.empty()) return fail(ctx, code, err);
-  const FlatScene& f = ctx->flat;
+  int rc = upload_flat(ctx);
+  // the members of a device group get the same flattened scene: built once, copied to each
+  for (rt_ctx* peer : ctx->peers) {
+    if (rc != RT_OK) break;
+    peer->flat_ptr = ctx->flat_ptr;
+    rc = upload_flat(peer);
+    if (rc != RT_OK) ctx->error = "device " + std::to_string(peer->device) + ": " + peer->error;
+  }
+  return rc;
+}
+
+// The device side of rt_upload_scene for one context: ctx->flat_ptr to device memory, LDS plans.
+static int upload_flat(rt_ctx* ctx) {
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  ctx->have_scene = false;
+  const FlatScene& f = ctx->flat();
   int rc;
   {
     // device copy of the records: the traversal entry code in place of `a`, and three
@@ -1620,6 +1726,8 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* scene) {
 int rt_render_f64(rt_ctx* ctx, const rt_render_params* p, double* rgb_sum, uint64_t* stats) {
   if (!ctx) return RT_ERR_INVALID;
   if (!rgb_sum) return fail(ctx, RT_ERR_INVALID, "null output");
+  if (!ctx->peers.empty())
+    return fail(ctx, RT_ERR_UNSUPPORTED, "rt_render_f64: a device group adds float shares (use rt_render)");
   double* accum = nullptr;
   int rc = render_into_accum(ctx, p, stats, &accum);
   if (rc != RT_OK) return rc;
@@ -1640,11 +1748,101 @@ static int output_on_device(rt_ctx* ctx, const void* d_out) {
   return RT_OK;
 }
 
+
+// A device group's render: member k of N renders samples [begin + n k / N, begin + n (k + 1) / N)
+// of every pixel on its own device and stream, from its own host thread; the float shares are
+// then added onto the root's device: one ncclReduce(sum) to rank 0 over the group's communicators
+// (RCCL; between the GPUs of one node that is xGMI), or through host memory for a group
+// without communicators.  d_out: window-sized float sums on the root's device.  Replaces the
+// per-pixel `.sum()` over samples (src/main.rs:97) across devices: the only coupling there is.
+static int render_group(rt_ctx* root, const rt_render_params* p, float* d_out, uint64_t* stats) {
+  if (!p) return fail(root, RT_ERR_INVALID, "null params");
+  if (p->sample_end < p->sample_begin) return fail(root, RT_ERR_INVALID, "empty sample range");
+  std::vector<rt_ctx*> members{root};
+  members.insert(members.end(), root->peers.begin(), root->peers.end());
+  const uint32_t N = (uint32_t)members.size();
+  PassInfo ps{};
+  int rc = check_window(root, p->width, p->height, &p->window, ps);
+  if (rc != RT_OK) return rc;
+  const uint64_t n = (uint64_t)ps.n_pixels * 3;
+  const uint64_t total = p->sample_end - p->sample_begin;
+  std::vector<int> codes(N, RT_OK);
+  std::vector<std::vector<uint64_t>> member_stats(N, std::vector<uint64_t>(stats ? RT_STAT_COUNT : 0));
+  auto work = [&](uint32_t k) {
+    rt_ctx* m = members[k];
+    auto run = [&]() -> int {
+      RT_HIP(m, hipSetDevice(m->device));
+      if (m->share.n < n) {
+        m->share.release();
+        RT_HIP(m, hipMalloc((void**)&m->share.p, n * sizeof(float)));
+        m->share.n = n;
+      }
+      rt_render_params pk = *p;
+      pk.sample_begin = p->sample_begin + (uint32_t)(total * k / N);
+      pk.sample_end = p->sample_begin + (uint32_t)(total * (k + 1) / N);
+      double* accum = nullptr;
+      int r = render_into_accum(m, &pk, stats ? member_stats[k].data() : nullptr, &accum);
+      if (r != RT_OK) return r;
+      to_float_kernel<<<blocks_for(n), kBlock, 0, m->stream>>>(accum, m->share.p, n);
+      RT_HIP(m, hipGetLastError());
+      RT_HIP(m, hipStreamSynchronize(m->stream));
+      return RT_OK;
+    };
+    codes[k] = run();
+  };
+  {
+    std::vector<std::thread> threads;
+    for (uint32_t k = 1; k < N; ++k) threads.emplace_back(work, k);
+    work(0);
+    for (std::thread& t : threads) t.join();
+  }
+  for (uint32_t k = 0; k < N; ++k)
+    if (codes[k] != RT_OK)
+      return fail(root, codes[k], "device " + std::to_string(members[k]->device) + ": " + members[k]->error);
+  if (stats) {
+    for (int i = 0; i < RT_STAT_COUNT; ++i) {
+      stats[i] = 0;
+      for (uint32_t k = 0; k < N; ++k) stats[i] += member_stats[k][i];
+    }
+  }
+  if (!root->comms.empty()) {
+    Rccl r;
+    if (!load_rccl(root->rccl, r)) return fail(root, RT_ERR_DEVICE, "librccl lost its symbols");
+    int nrc = r.GroupStart();
+    for (uint32_t k = 0; k < N && nrc == 0; ++k) {
+      RT_HIP(root, hipSetDevice(members[k]->device));
+      nrc = r.Reduce(members[k]->share.p, k == 0 ? (void*)d_out : (void*)members[k]->share.p, n, kNcclFloat,
+                     kNcclSum, 0, root->comms[k], members[k]->stream);
+    }
+    int erc = r.GroupEnd();
+    if (nrc == 0) nrc = erc;
+    if (nrc != 0) return fail(root, RT_ERR_DEVICE, std::string("ncclReduce: ") + r.GetErrorString(nrc));
+    for (uint32_t k = 0; k < N; ++k) {
+      RT_HIP(root, hipSetDevice(members[k]->device));
+      RT_HIP(root, hipStreamSynchronize(members[k]->stream));
+    }
+    RT_HIP(root, hipSetDevice(root->device));
+  } else {
+    std::vector<float> sum(n), part(n);
+    for (uint32_t k = 0; k < N; ++k) {
+      RT_HIP(root, hipSetDevice(members[k]->device));
+      RT_HIP(root, hipMemcpy(k == 0 ? sum.data() : part.data(), members[k]->share.p, n * sizeof(float),
+                             hipMemcpyDeviceToHost));
+      if (k)
+        for (uint64_t i = 0; i < n; ++i) sum[i] += part[i];
+    }
+    RT_HIP(root, hipSetDevice(root->device));
+    RT_HIP(root, hipMemcpy(d_out, sum.data(), n * sizeof(float), hipMemcpyHostToDevice));
+  }
+  return RT_OK;
+}
+
 int rt_render_device(rt_ctx* ctx, const rt_render_params* p, float* d_rgb_sum, uint64_t* stats) {
   if (!ctx) return RT_ERR_INVALID;
   if (!d_rgb_sum) return fail(ctx, RT_ERR_INVALID, "null output");
   int rc = output_on_device(ctx, d_rgb_sum);
   if (rc != RT_OK) return rc;
+  if (!ctx->peers.empty()) return render_group(ctx, p, d_rgb_sum, stats);
   double* accum = nullptr;
   rc = render_into_accum(ctx, p, stats, &accum);
   if (rc != RT_OK) return rc;
@@ -1660,6 +1858,7 @@ int rt_render_device(rt_ctx* ctx, const rt_render_params* p, float* d_rgb_sum, u
 int rt_render_device_noalloc(rt_ctx* ctx, const rt_render_params* p, float* d_rgb_sum) {
   if (!ctx) return RT_ERR_INVALID;
   if (!d_rgb_sum) return fail(ctx, RT_ERR_INVALID, "null output");
+  if (!ctx->peers.empty()) return fail(ctx, RT_ERR_UNSUPPORTED, "rt_render_device_noalloc: not for device groups");
   int rc = output_on_device(ctx, d_rgb_sum);
   if (rc != RT_OK) return rc;
   double* accum = nullptr;
@@ -1687,6 +1886,18 @@ static int ensure_staging(rt_ctx* ctx, size_t bytes) {
 int rt_render(rt_ctx* ctx, const rt_render_params* p, float* rgb_sum, uint64_t* stats) {
   if (!ctx) return RT_ERR_INVALID;
   if (!rgb_sum) return fail(ctx, RT_ERR_INVALID, "null output");
+  if (!ctx->peers.empty()) {
+    if (!p) return fail(ctx, RT_ERR_INVALID, "null params");
+    PassInfo gps{};
+    int grc = check_window(ctx, p->width, p->height, &p->window, gps);
+    if (grc != RT_OK) return grc;
+    const uint64_t gn = (uint64_t)gps.n_pixels * 3;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    if ((grc = ensure_staging(ctx, gn * sizeof(float))) != RT_OK) return grc;
+    if ((grc = render_group(ctx, p, (float*)ctx->staging.p, stats)) != RT_OK) return grc;
+    RT_HIP(ctx, hipMemcpy(rgb_sum, ctx->staging.p, gn * sizeof(float), hipMemcpyDeviceToHost));
+    return RT_OK;
+  }
   double* accum = nullptr;
   int rc = render_into_accum(ctx, p, stats, &accum);
   if (rc != RT_OK) return rc;
@@ -1717,7 +1928,7 @@ int rt_first_hit(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_window* 
   double* d_t = d_n + 3 * n;
   uint32_t* d_id = (uint32_t*)(d_t + n);
   const uint32_t fgrid = std::min(blocks_for(n), ctx->n_cus * ctx->blocks_per_cu);
-  with_bool(!ctx->flat.chain_ranges.empty(), [&](auto C) {
+  with_bool(!ctx->flat().chain_ranges.empty(), [&](auto C) {
     return with_bool(ctx->lds.overflow != nullptr, [&](auto O) {
       first_hit_kernel<decltype(C)::value, decltype(O)::value>
           <<<fgrid, kBlock, ctx->lds.bytes, ctx->stream>>>(ctx->ds, ctx->lds, ps, d_id, d_t, d_n);
@@ -1776,7 +1987,16 @@ const char* rt_last_error(const rt_ctx* ctx) { return ctx ? ctx->error.c_str() :
 
 void rt_destroy(rt_ctx* ctx) {
   if (!ctx) return;
+  if (!ctx->comms.empty()) {
+    Rccl r;
+    if (load_rccl(ctx->rccl, r))
+      for (void* c : ctx->comms)
+        if (c) (void)r.CommDestroy(c);
+  }
+  if (ctx->rccl) dlclose(ctx->rccl);
+  for (rt_ctx* peer : ctx->peers) rt_destroy(peer);
   (void)hipSetDevice(ctx->device);
+  ctx->share.release();
   free_paths(ctx);
   ctx->nodes.release();
   ctx->prims.release();

@@ -24,7 +24,18 @@ def render_sharded(render_fn, out, sample_begin, sample_end, rank, world, dist=N
     or None for a single process.
     """
     lo, hi = shard_samples(sample_begin, sample_end, rank, world)
+    # render_fn writes `out` on the library's own stream and returns when that is done; what
+    # torch still has queued on `out` (a fill, the previous step's reduce) must be over before
+    # it starts, and the reduce must be over before the caller reads or the next step overwrites
+    def settle():
+        if out.is_cuda:
+            import torch
+            torch.cuda.current_stream(out.device).synchronize()
+
+    settle()
     render_fn(lo, hi, out)
     if dist is not None and world > 1:
-        dist.reduce(out, dst=0, op=dist.ReduceOp.SUM)
+        work = dist.reduce(out, dst=0, op=dist.ReduceOp.SUM, async_op=True)
+        work.wait()
+        settle()
     return lo, hi

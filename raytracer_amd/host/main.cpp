@@ -15,7 +15,13 @@ static void usage() {
   std::fprintf(stderr,
                "usage: raytracer <scene.ron|scene.rtscene> [--width N] [--height N] [--spp N]\n"
                "       [--max-depth N] [--seed N] [--scene-seed N] [--device N] [--out image.png]\n"
-               "       [--assets DIR] [--freeze out.rtscene]\n");
+               "       [--assets DIR] [--freeze out.rtscene] [--gpus N | --devices a,b,...]\n"
+               "       [--dump-pfm linear.pfm] [--first-hit hits.rtfh]\n"
+               "  --gpus N         render on devices 0..N-1 (sample ranges, one reduce onto device 0)\n"
+               "  --dump-pfm F     also write the linear per-pixel mean radiance (before the clamp and the\n"
+               "                   8-bit resolve) as a little-endian RGB PFM\n"
+               "  --first-hit F    also write the pinhole pixel-centre first-hit pass: 'RTFH', width, height\n"
+               "                   (u32), then ids (u32), t (f64) and normals (3 f64) per pixel, row 0 on top\n");
 }
 
 int main(int argc, char** argv) {
@@ -23,7 +29,8 @@ int main(int argc, char** argv) {
     usage();
     return 2;
   }
-  std::string path, out = "image.png", freeze;
+  std::string path, out = "image.png", freeze, pfm, first_hit;
+  std::vector<int32_t> devices;
   rt_host_options opt{};
   opt.scene_seed = 1;
   uint64_t seed = 1;
@@ -47,6 +54,19 @@ int main(int argc, char** argv) {
     else if (a == "--out") out = next("--out");
     else if (a == "--assets") rt_host_add_asset_dir(next("--assets"));
     else if (a == "--freeze") freeze = next("--freeze");
+    else if (a == "--dump-pfm") pfm = next("--dump-pfm");
+    else if (a == "--first-hit") first_hit = next("--first-hit");
+    else if (a == "--gpus") {
+      int n = std::atoi(next("--gpus"));
+      devices.clear();
+      for (int k = 0; k < n; ++k) devices.push_back(k);
+    } else if (a == "--devices") {
+      devices.clear();
+      for (const char* c = next("--devices"); *c;) {
+        devices.push_back((int32_t)std::strtol(c, const_cast<char**>(&c), 10));
+        if (*c == ',') ++c;
+      }
+    }
     else if (a == "-h" || a == "--help") {
       usage();
       return 0;
@@ -87,9 +107,11 @@ int main(int argc, char** argv) {
 
   rt_ctx* ctx = nullptr;
   rt_config cfg{};
-  cfg.device = device;
+  cfg.device = devices.empty() ? device : devices[0];
+  cfg.n_devices = (uint32_t)devices.size();
+  cfg.devices = devices.empty() ? nullptr : devices.data();
   if (rt_create(&cfg, &ctx) != RT_OK) {
-    std::fprintf(stderr, "Error: no usable HIP device %d\n", device);
+    std::fprintf(stderr, "Error: no usable HIP device %d (or device group)\n", cfg.device);
     return 1;
   }
   if (rt_upload_scene(ctx, view) != RT_OK) {
@@ -105,9 +127,50 @@ int main(int argc, char** argv) {
   p.sample_end = spp;
   p.max_depth = depth;
   p.seed = seed;
-  if (rt_render_f64(ctx, &p, sum.data(), nullptr) != RT_OK) {
+  if (devices.size() > 1) {  // a device group adds float shares
+    std::vector<float> fsum(sum.size());
+    if (rt_render(ctx, &p, fsum.data(), nullptr) != RT_OK) {
+      std::fprintf(stderr, "Error: %s\n", rt_last_error(ctx));
+      return 1;
+    }
+    for (size_t i = 0; i < sum.size(); ++i) sum[i] = (double)fsum[i];
+  } else if (rt_render_f64(ctx, &p, sum.data(), nullptr) != RT_OK) {
     std::fprintf(stderr, "Error: %s\n", rt_last_error(ctx));
     return 1;
+  }
+  if (!pfm.empty()) {  // PFM rows run bottom to top; a negative scale means little-endian
+    FILE* f = std::fopen(pfm.c_str(), "wb");
+    if (!f) {
+      std::fprintf(stderr, "Error: cannot write %s\n", pfm.c_str());
+      return 1;
+    }
+    std::fprintf(f, "PF\n%u %u\n-1.0\n", w, h);
+    std::vector<float> row((size_t)w * 3);
+    for (uint32_t y = h; y-- > 0;) {
+      for (size_t i = 0; i < row.size(); ++i) row[i] = (float)(sum[(size_t)y * w * 3 + i] / (double)spp);
+      std::fwrite(row.data(), sizeof(float), row.size(), f);
+    }
+    std::fclose(f);
+  }
+  if (!first_hit.empty()) {
+    std::vector<uint32_t> id((size_t)w * h);
+    std::vector<double> t((size_t)w * h), normal((size_t)w * h * 3);
+    if (rt_first_hit(ctx, w, h, nullptr, id.data(), t.data(), normal.data()) != RT_OK) {
+      std::fprintf(stderr, "Error: %s\n", rt_last_error(ctx));
+      return 1;
+    }
+    FILE* f = std::fopen(first_hit.c_str(), "wb");
+    if (!f) {
+      std::fprintf(stderr, "Error: cannot write %s\n", first_hit.c_str());
+      return 1;
+    }
+    std::fwrite("RTFH", 1, 4, f);
+    std::fwrite(&w, 4, 1, f);
+    std::fwrite(&h, 4, 1, f);
+    std::fwrite(id.data(), 4, id.size(), f);
+    std::fwrite(t.data(), 8, t.size(), f);
+    std::fwrite(normal.data(), 8, normal.size(), f);
+    std::fclose(f);
   }
   std::vector<uint8_t> rgb((size_t)w * h * 3);
   rt_host_resolve_srgb8(sum.data(), (uint64_t)w * h, spp, rgb.data());

@@ -13,10 +13,16 @@ from . import abi
 
 
 class Context:
-    def __init__(self, device=0, max_paths_in_flight=0):
+    def __init__(self, device=0, max_paths_in_flight=0, devices=None):
+        """devices: a list of HIP ordinals makes a device group (devices[0] is the root)."""
         self._h = C.c_void_p()
         L = abi.device_lib()
-        cfg = abi.Config(device, 0, max_paths_in_flight)
+        if devices:
+            self._devices = (C.c_int32 * len(devices))(*devices)
+            device = devices[0]
+            cfg = abi.Config(device, len(devices), max_paths_in_flight, self._devices)
+        else:
+            cfg = abi.Config(device, 0, max_paths_in_flight, None)
         code = L.rt_create(C.byref(cfg), C.byref(self._h))
         if code != abi.RT_OK:
             self._h = None
