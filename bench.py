@@ -58,6 +58,7 @@ F_SHADE = {"shade_lambertian": 40, "shade_metal": 55, "shade_dielectric": 80, "s
            "shade_isotropic": 30, "shade_miss": 6}
 F_TEX = {"tex_checker": 15, "tex_image": 8, "tex_perlin": 900}
 PEAK_F64_TFLOPS = 78.6  # MI355X vector FP64 (spec)
+PEAK_F32_TFLOPS = 157.3  # MI355X vector FP32 (spec): the slab tests run in f32
 
 
 def extend_flops(st):
@@ -180,6 +181,11 @@ def main():
         fused = shade_s < 0.05 * ext_s
         flops_per_step = extend_flops(st) + (shade_flops(st) if fused else 0.0)
         achieved = flops_per_step * args.steps / ext_s / 1e12 if ext_s > 0 else 0.0
+        # the same time split by what each part of the work is rated against: the box tests run
+        # in f32 (157.3 TFLOP/s peak), everything else in f64 (78.6)
+        box_flops = float(st[abi.STAT_NAMES.index("box_tests")]) * F_BOX
+        ideal_s = (box_flops / (PEAK_F32_TFLOPS * 1e12) + (flops_per_step - box_flops) / (PEAK_F64_TFLOPS * 1e12))
+        frac_mixed = ideal_s * args.steps / ext_s if ext_s > 0 else 0.0
         rays = float(st[abi.STAT_NAMES.index("rays")])
         result["roofline"] = {
             "bound": "valu",
@@ -188,6 +194,7 @@ def main():
             "peak": PEAK_F64_TFLOPS,
             "unit": "TFLOP/s",
             "frac": achieved / PEAK_F64_TFLOPS,
+            "frac_mixed_peak": frac_mixed,
             "traffic": None,
             "launches": int(ext_launches),
             "avg_launch_ms": 1e3 * ext_s / max(ext_launches, 1),
@@ -201,7 +208,7 @@ def main():
         }
         # HBM bytes per launch come from separate rocprofv3 counter passes over the same kernel and
         # pass size (committed next to the kernel-trace summary); the counters cannot run in here
-        tpath = os.path.join(ROOT, "profiles", "r01_trace_kernel_hbm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r02_trace_kernel_hbm_traffic.json")
         if fused and os.path.exists(tpath) and (args.width, args.height) == (WIDTH, HEIGHT) and args.spp >= 64:
             with open(tpath) as f:
                 result["roofline"]["traffic"] = json.load(f)["hbm_bytes_per_launch"]
@@ -210,7 +217,7 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import pyoracle as po
             o = po.Oracle(scene.view_ptr)
-            cores = min(16, po.hardware_threads())
+            cores = po.hardware_threads()  # every host core this process may use
             # bounded sample of the same workload: the whole frame at 8 spp (~5 s on 16 cores)
             cpu_full_spp = 8
             pf = po.make_params(args.width, args.height, 0, cpu_full_spp, depth, SEED)

@@ -185,3 +185,22 @@ def test_threaded_build_equals_the_serial_one(monkeypatch):
     nodes2, items2, depth2 = build_bvh(scene)
     assert len(items1) == 40004 and depth1 == depth2
     assert np.array_equal(nodes1, nodes2) and np.array_equal(items1, items2)
+
+
+def test_rust_mirror_follows_the_header():
+    """rust/mi355rt-sys cannot be compiled here; its structs, sizes and symbols are held to the ctypes mirror."""
+    import re
+    text = open(os.path.join(ROOT, "rust", "mi355rt-sys", "src", "lib.rs")).read()
+    mirror = {"rt_camera": abi.Camera, "rt_camera_desc": abi.CameraDesc, "rt_prim": abi.Prim, "rt_op": abi.Op,
+              "rt_object": abi.Object, "rt_material": abi.Material, "rt_texture": abi.Texture,
+              "rt_perlin": abi.Perlin, "rt_image": abi.Image, "rt_scene": abi.Scene,
+              "rt_host_options": abi.HostOptions, "rt_config": abi.Config, "rt_window": abi.Window,
+              "rt_render_params": abi.RenderParams, "rt_bvh_node": abi.BvhNode, "rt_bvh_item": abi.BvhItem}
+    for name, cls in mirror.items():
+        body = re.search(r"pub struct %s \{(.*?)\n\}" % name, text, re.S).group(1)
+        fields = re.findall(r"pub (\w+):", body)
+        assert fields == [f[0] for f in cls._fields_], name
+        size = re.search(r"size_of::<%s>\(\) == ([^)]+)\)" % name, text).group(1)
+        assert eval(size) == C.sizeof(cls), name
+    fns = set(re.findall(r"pub fn (rt_\w+)\(", text))
+    assert fns == set(abi.HOST_SYMBOLS + abi.DEVICE_SYMBOLS)
