@@ -14,6 +14,7 @@
 // were passed" and its box test (src/geom/aabb.rs:35-50) never rejects a true
 // hit.
 #include <algorithm>
+#include <chrono>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -160,25 +161,70 @@ bool of_less(double a, double b) {
   return a < b;
 }
 
-// Objects in the order the reference prefers among equal-t hits.
-void reference_order(const std::vector<Box>& boxes, std::vector<uint32_t>& ids, int axis,
-                     std::vector<uint32_t>& out) {
-  const size_t kMaxPerLeaf = 256;  // bvh.rs:9
-  if (ids.size() < kMaxPerLeaf) {
-    out.insert(out.end(), ids.begin(), ids.end());
+// Stable sort of [first, last) on up to `threads` threads: halves sorted side by side, then merged
+// (std::inplace_merge keeps equal elements in order, so the result is std::stable_sort's).
+template <typename It, typename Less>
+void parallel_stable_sort(It first, It last, Less less, unsigned threads) {
+  const size_t n = (size_t)(last - first);
+  if (threads < 2 || n < (1u << 14)) {
+    std::stable_sort(first, last, less);
     return;
   }
-  std::stable_sort(ids.begin(), ids.end(), [&](uint32_t a, uint32_t b) {
-    double ka = (boxes[a].lo[axis] + boxes[a].hi[axis]) / 2.0;
-    double kb = (boxes[b].lo[axis] + boxes[b].hi[axis]) / 2.0;
-    return of_less(ka, kb);
-  });
-  size_t half = ids.size() / 2;
-  std::vector<uint32_t> left(ids.begin(), ids.begin() + (long)half);
-  std::vector<uint32_t> right(ids.begin() + (long)half, ids.end());
-  int next = (axis + 1) % 3;
-  reference_order(boxes, right, next, out);  // the right subtree wins ties
-  reference_order(boxes, left, next, out);
+  It mid = first + (long)(n / 2);
+  std::thread worker([&] { parallel_stable_sort(first, mid, less, threads / 2); });
+  parallel_stable_sort(mid, last, less, threads - threads / 2);
+  worker.join();
+  std::inplace_merge(first, mid, last, less);
+}
+
+// Objects in the order the reference prefers among equal-t hits: BvhNode::new_along_axis
+// (bvh.rs:33-77) sorts its objects by box centre along the axis (stable, NaN last), gives the
+// upper half to the right child and the lower half to the left, and moves on to the next axis;
+// among equal t the right subtree wins (bvh.rs:93-97) and, in a leaf list, the earlier object
+// (hittable_list.rs:31).  A range of the id array is sorted in place and its two halves are
+// ordered side by side: the right half's objects come first in `out`, so where each half
+// writes is known before either starts.
+struct RefOrder {
+  struct Keyed {
+    double key;
+    uint32_t id;
+  };
+  const std::vector<Box>& boxes;
+  std::vector<uint32_t>& out;
+  void run(Keyed* ids, size_t n, int axis, size_t out_at, unsigned threads) {
+    const size_t kMaxPerLeaf = 256;  // bvh.rs:9
+    if (n < kMaxPerLeaf) {
+      for (size_t i = 0; i < n; ++i) out[out_at + i] = ids[i].id;
+      return;
+    }
+    for (size_t i = 0; i < n; ++i) {
+      const Box& b = boxes[ids[i].id];
+      ids[i].key = (b.lo[axis] + b.hi[axis]) / 2.0;
+    }
+    parallel_stable_sort(ids, ids + n, [](const Keyed& a, const Keyed& b) { return of_less(a.key, b.key); },
+                         threads);
+    const size_t half = n / 2;
+    const int next = (axis + 1) % 3;
+    // the right subtree (upper half) wins ties: it comes first
+    if (threads >= 2 && n >= (1u << 14)) {
+      std::thread worker([&] { run(ids + half, n - half, next, out_at, threads / 2); });
+      run(ids, half, next, out_at + (n - half), threads - threads / 2);
+      worker.join();
+    } else {
+      run(ids + half, n - half, next, out_at, 1);
+      run(ids, half, next, out_at + (n - half), 1);
+    }
+  }
+};
+void reference_order(const std::vector<Box>& boxes, std::vector<uint32_t>& ids, int axis,
+                     std::vector<uint32_t>& out) {
+  std::vector<RefOrder::Keyed> keyed(ids.size());
+  for (size_t i = 0; i < ids.size(); ++i) keyed[i] = RefOrder::Keyed{0.0, ids[i]};
+  const size_t at = out.size();
+  out.resize(at + ids.size());
+  unsigned threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  if (const char* e = getenv("MI355RT_BUILD_THREADS")) threads = std::max(1ul, strtoul(e, nullptr, 10));
+  RefOrder{boxes, out}.run(keyed.data(), keyed.size(), axis, at, threads);
 }
 
 // The box chains of the reference's hierarchy (bvh.rs:33-77): one chain per leaf list, the
@@ -335,29 +381,32 @@ struct Builder {
     size_t mid = begin;
     bool have_split = false;
 
-    // small ranges: exact SAH, every split position of the centroid order on every axis
+    // small ranges: exact SAH, every split position of the centroid order on every axis.
+    // The orders are kept as (centroid, position) pairs: the 80-byte items move once, into the
+    // order of the winning axis (the same order a stable sort of the items themselves gives).
     if (count <= sweep_max) {
       double best_cost = INF;
       int best_axis = -1;
       size_t best_left = 0;
-      std::vector<double> right_area(count);
-      auto by_axis = [&](int a) {
-        std::stable_sort(items.begin() + (long)begin, items.begin() + (long)end,
-                         [a](const BuildItem& x, const BuildItem& y) {
-                           return x.centroid[a] < y.centroid[a];
-                         });
+      struct Key {
+        double c;
+        uint32_t at;
       };
+      std::vector<double> right_area(count);
+      std::vector<Key> order(count), best_order;
       for (int a = 0; a < 3; ++a) {
         if (!(cbounds.hi[a] > cbounds.lo[a])) continue;
-        by_axis(a);
+        for (size_t i = 0; i < count; ++i) order[i] = Key{items[begin + i].centroid[a], (uint32_t)i};
+        std::stable_sort(order.begin(), order.end(), [](const Key& x, const Key& y) { return x.c < y.c; });
         Box acc;
         for (size_t i = count; i-- > 1;) {
-          acc.grow(items[begin + i].box);
+          acc.grow(items[begin + order[i].at].box);
           right_area[i] = acc.area();
         }
         Box lacc;
+        bool won = false;
         for (size_t l = 1; l < count; ++l) {  // l items on the left
-          lacc.grow(items[begin + l - 1].box);
+          lacc.grow(items[begin + order[l - 1].at].box);
           size_t r = count - l;
           if ((double)std::min(l, r) < min_side * (double)count) continue;
           if (!fits(l, levels_left) || !fits(r, levels_left)) continue;
@@ -366,11 +415,15 @@ struct Builder {
             best_cost = cost;
             best_axis = a;
             best_left = l;
+            won = true;
           }
         }
+        if (won) best_order = order;
       }
       if (best_axis >= 0) {
-        by_axis(best_axis);
+        std::vector<BuildItem> moved(count);
+        for (size_t i = 0; i < count; ++i) moved[i] = items[begin + best_order[i].at];
+        std::copy(moved.begin(), moved.end(), items.begin() + (long)begin);
         mid = begin + best_left;
         have_split = true;
       }
@@ -482,7 +535,7 @@ struct Builder {
   }
 
   static constexpr size_t kParallelMin = 1u << 15;  // items
-  static constexpr uint32_t kParallelDepth = 3;     // up to eight threads
+  static constexpr uint32_t kParallelDepth = 4;     // up to sixteen threads
 
   // Put a subtree built on its own (root at sub[0], leaf slots counted from 0) at node `slot`.
   void splice(uint32_t slot, const std::vector<BinNode>& sub, const std::vector<uint32_t>& sub_leaves) {
@@ -568,6 +621,16 @@ uint32_t pack_ops(uint32_t first, uint32_t count) { return (first & 0x00FFFFFFu)
 }  // namespace
 
 std::string flatten_scene(const rt_scene& s, FlatScene& out, int& code) {
+  // MI355RT_DEBUG: where the time of a flatten goes
+  const bool timing = getenv("MI355RT_DEBUG") != nullptr;
+  auto clock0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "mi355rt: flatten %-22s %8.1f ms\n", what,
+            std::chrono::duration<double, std::milli>(now - clock0).count());
+    clock0 = now;
+  };
   code = RT_ERR_INVALID;
   std::string bad = validate_scene(s);
   if (!bad.empty()) return "invalid scene: " + bad;
@@ -626,6 +689,7 @@ std::string flatten_scene(const rt_scene& s, FlatScene& out, int& code) {
     out.ops[i] = d;
   }
 
+  lap("materials, ops");
   // reference preference order -> rank of the first primitive of every object
   std::vector<Box> ref_boxes(s.n_objects);
   for (uint32_t i = 0; i < s.n_objects; ++i) ref_boxes[i] = ref_object_box(s, s.objects[i], t0, t1);
@@ -646,6 +710,7 @@ std::string flatten_scene(const rt_scene& s, FlatScene& out, int& code) {
     }
   }
 
+  lap("reference order");
   // box chains of the reference's hierarchy, only for scenes that need them
   RefChains chains;
   {
@@ -777,6 +842,7 @@ std::string flatten_scene(const rt_scene& s, FlatScene& out, int& code) {
       bi.centroid[a] = std::isfinite(c) ? c : 0.0;
     }
 
+  lap("records, boxes");
   if (!build_items.empty()) {
     std::vector<BinNode> bin;
     bin.reserve(build_items.size() * 2);
@@ -796,7 +862,9 @@ std::string flatten_scene(const rt_scene& s, FlatScene& out, int& code) {
       if (v >= 1 && v <= kMaxLeafItems) b.max_leaf = (uint32_t)v;
     }
     b.build(0, 0, build_items.size(), 0);
+    lap("SAH build");
     out.stack_entries = collapse_wide(bin, out.nodes, out.bvh_depth);
+    lap("collapse");
     out.prims.reserve(leaf_order.size());
     for (uint32_t slot : leaf_order) {
       out.prims.push_back(slots[slot]);
@@ -804,6 +872,7 @@ std::string flatten_scene(const rt_scene& s, FlatScene& out, int& code) {
       out.ranks.push_back(slot_items[slot].rank);
     }
   }
+  lap("leaf order");
   if (out.items.size() >= (1u << 26) || out.nodes.size() >= (1u << 27)) {
     code = RT_ERR_LIMIT;
     return "acceleration structure too large for the packed traversal entries";
