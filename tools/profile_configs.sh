@@ -1,0 +1,16 @@
+# usage: bash tools/profile_configs.sh <round-tag>   (on the GPU box: work/time/roofline and rocprofv3 summaries per configuration)
+set -e
+R=${1:-r02}
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/$R
+run() {  # name scene spp w h
+  echo "== $1: roofline"; timeout -k 10 300 python3 -u tools/config_roofline.py $2 $3 $4 $5 gpurun_out/$R/${R}_$1_roofline.json > gpurun_out/$R/$1_roofline.log 2>&1
+  echo "== $1: rocprofv3"; bash tools/profile.sh ${R}_$1 $2 $3 $4 $5
+  python3 tools/prof_summary.py gpurun_out/prof_${R}_$1 > gpurun_out/$R/${R}_$1_rocprof.txt
+  rm -rf gpurun_out/prof_${R}_$1
+}
+run book_cover book_cover 64 1920 1080
+run cornell cornell 64 1024 1024
+run book2 book2 64 1920 1080
+run cover1m cover1m 16 3840 2160
+ls -la gpurun_out/$R
