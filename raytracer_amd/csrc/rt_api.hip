@@ -1161,7 +1161,13 @@ LdsLayout plan_lds(const FlatScene& f, uint32_t block, uint32_t budget, uint32_t
   const uint32_t need = std::max(f.stack_entries + 1u, 2u);
   l.stack_depth = std::min(need, std::max(stack_cap, 2u));
   l.entry_bits = entry_code_bits((uint32_t)f.nodes.size(), (uint32_t)f.items.size());
-  uint32_t used = l.stack_depth * block * (uint32_t)sizeof(uint32_t);
+  // rows for the leaf slots a traversal sets aside (constant media, records tied to the
+  // reference's box chain): as many as a ray can meet, eight at most (a full list is settled
+  // mid-traversal), none for scenes without such records
+  uint32_t flagged = 0;
+  for (const DPrim& pr : f.prims) flagged += ((pr.kind & 15u) == DP_MEDIUM || (pr.kind & kChainBit)) ? 1u : 0u;
+  l.cand_rows = std::min(flagged, 8u);
+  uint32_t used = (l.stack_depth + l.cand_rows) * block * (uint32_t)sizeof(uint32_t);
   budget = std::max(budget, used + 4096u);  // leave room for a few records
   uint32_t room = budget - used;
   // (+3: the never-hit records that end the device copy, so the last group stays in LDS)
@@ -1683,7 +1689,7 @@ static int upload_flat(rt_ctx* ctx) {
     if (tb != 256u && tb != 512u)
       return fail(ctx, RT_ERR_INVALID, "MI355RT_TRACE_BLOCK must be 256 or 512");
     ctx->trace_block = tb;
-    const uint32_t per_cu = ctx->general ? (tb == 256u ? 3u : 1u) : 1024u / tb;  // resident
+    const uint32_t per_cu = std::max(1u, (ctx->general ? 256u * RT_TRACE_MEDIA_WAVES : 1024u) / tb);  // resident
     // launched: as many workgroups as are resident together; the waves draw their work from a
     // counter, so nothing is gained by more
     ctx->trace_blocks_per_cu = per_cu;

@@ -457,6 +457,7 @@ struct LdsLayout {
   uint32_t n_nodes;      // nodes [0, n_nodes) are in LDS
   uint32_t n_prims;      // leaf slots [0, n_prims) are in LDS
   uint32_t stack_depth;  // stack entries per lane held in LDS
+  uint32_t cand_rows;    // rows after the stack: leaf slots whose test waits for the end of the traversal
   uint32_t bytes;        // total dynamic LDS bytes per workgroup
   uint32_t entry_bits;   // bits of a traversal entry code (see entry_code_bits)
   // Hierarchies whose worst-case stack need exceeds stack_depth: entries from index
@@ -477,6 +478,7 @@ struct LdsScene {
   lds_u32* stack;          // this lane's column of packed entries, `stack_stride` words apart
   uint32_t n_nodes, n_prims, stack_stride, entry_bits;
   uint32_t stack_cap;      // entries of the column that exist in LDS
+  uint32_t cand_cap;       // rows [stack_cap, stack_cap + cand_cap) of the column: postponed leaf slots
   uint32_t* overflow;      // this lane's column of the global overflow area, or null (uniform)
   uint32_t overflow_stride;
 };
@@ -502,6 +504,7 @@ RT_DEV LdsScene lds_stage(const DeviceScene& sc, const LdsLayout& lay, char* sme
   l.stack_stride = block;
   l.entry_bits = lay.entry_bits;
   l.stack_cap = lay.stack_depth;
+  l.cand_cap = lay.cand_rows;
   l.overflow = lay.overflow ? lay.overflow + (blockIdx.x * block + tid) : nullptr;
   l.overflow_stride = lay.overflow_stride;
   return l;
@@ -687,15 +690,8 @@ RT_DEV Closest closest_hit(const DeviceScene& sc, const LdsScene& lds, V3 o, V3 
   best.item = kNoPrim;
   best.kind = 0;
   if (sc.n_nodes == 0) return best;
-  // culling arithmetic: once per ray, then one FMA per slab plane
-  const CullAxis cx = cull_axis(o.x, d.x), cy = cull_axis(o.y, d.y), cz = cull_axis(o.z, d.z);
-  const float tmin32 = (float)tmin * 0.99f;
   float best32w = __int_as_float(0x7F800000);  // best t so far, times kWiden
   typedef float f32x2 __attribute__((ext_vector_type(2)));
-  // constants paired the way the record's words pair up: (lo.x lo.y) (lo.z hi.x) (hi.y hi.z)
-  const f32x2 mul_a = {cx.inv_lo, cy.inv_lo}, add_a = {cx.add_lo, cy.add_lo};
-  const f32x2 mul_b = {cz.inv_lo, cx.inv_hi}, add_b = {cz.add_lo, cx.add_hi};
-  const f32x2 mul_c = {cy.inv_hi, cz.inv_hi}, add_c = {cy.add_hi, cz.add_hi};
   const double dd = vlen2(d);
   const f32x4* gnodes = (const f32x4*)sc.nodes;
   uint32_t sp = 0;
@@ -724,6 +720,30 @@ RT_DEV Closest closest_hit(const DeviceScene& sc, const LdsScene& lds, V3 o, V3 
     return kNoEntry;
   };
 
+  auto take = [&](double t, uint32_t slot, uint32_t kind) {  // HittableList::hit's first minimum, by rank
+    if (t < best.t || (t == best.t && best.item != kNoPrim && sc.ranks[slot] < sc.ranks[best.item])) {
+      best.t = t;
+      best.item = slot;
+      best.kind = kind;
+      best32w = (float)t * kWiden;
+    }
+  };
+  uint32_t n_cand = 0;  // leaf slots set aside in rows [cap, cap + cand_cap) of the lane's column
+  do {
+  // culling arithmetic: once per ray, then one FMA per slab plane.  (Kernels that settle
+  // postponed slots between two stretches of the walk form the constants again for each
+  // stretch, from coordinates the optimiser cannot see through: held across the medium code
+  // they would cost a quarter of the register file for something that is almost never resumed.)
+  V3 oc = o, dc = d;
+  if (MEDIA || CHAINS) {
+    asm volatile("" : "+v"(oc.x), "+v"(oc.y), "+v"(oc.z), "+v"(dc.x), "+v"(dc.y), "+v"(dc.z));
+  }
+  const CullAxis cx = cull_axis(oc.x, dc.x), cy = cull_axis(oc.y, dc.y), cz = cull_axis(oc.z, dc.z);
+  const float tmin32 = (float)tmin * 0.99f;
+  // constants paired the way the record's words pair up: (lo.x lo.y) (lo.z hi.x) (hi.y hi.z)
+  const f32x2 mul_a = {cx.inv_lo, cy.inv_lo}, add_a = {cx.add_lo, cy.add_lo};
+  const f32x2 mul_b = {cz.inv_lo, cx.inv_hi}, add_b = {cz.add_lo, cx.add_hi};
+  const f32x2 mul_c = {cy.inv_hi, cz.inv_hi}, add_c = {cy.add_hi, cz.add_hi};
   for (;;) {
     RT_LP(st, LP_OUTER);
     // descend until the current entry is a leaf
@@ -784,34 +804,59 @@ RT_DEV Closest closest_hit(const DeviceScene& sc, const LdsScene& lds, V3 o, V3 
     }
     if (leaf == kNoEntry) break;
     const uint32_t leaf_first = leaf >> 4, leaf_count = ((leaf >> 1) & 7u) + 1u;
+    bool stopped = false;
     for (uint32_t k = 0; k < leaf_count; ++k) {
       RT_LP(st, LP_LEAFPRIM);
       uint32_t slot = leaf_first + k;
       const DPrim pr = load_prim<false>(sc, lds, slot);
       double t;
       bool hit;
-      bool overhang = true;  // (a flagged medium always answers to the chain)
-      if (MEDIA && (pr.kind & 15u) == DP_MEDIUM)
-        hit = medium_t<STATS>(sc, pr, o, d, time, tmin, inf, key, t, st);
-      else if (!MEDIA && (pr.kind & 15u) == DP_MEDIUM)
-        hit = false;
+      bool overhang = true;
+      const bool medium = (pr.kind & 15u) == DP_MEDIUM;
+      if (medium)
+        hit = MEDIA;  // (a scene's media are skipped by the kernels that do not carry them)
       else
         hit = base_prim_t<STATS>(sc, pr, o, d, dd, time, tmin, inf, t, st, overhang);
-      if (CHAINS && hit && (pr.kind & kChainBit) && overhang)  // a hit outside its object's box
-        hit = reference_chain_passes(sc, (uint32_t)((pr.kind & 15u) == DP_MEDIUM ? pr.p[3] : pr.p5), o, d,
-                                     tmin);
-      if (hit) {
-        if (t < best.t || (t == best.t && best.item != kNoPrim &&
-                           sc.ranks[slot] < sc.ranks[best.item])) {
-          best.t = t;
-          best.item = slot;
-          best.kind = pr.kind;
-          best32w = (float)t * kWiden;
+      // A constant medium, or a hit outside its object's box (answerable only by the reference's
+      // own box chain), is set aside: its slot goes to the lane's list and is settled once the
+      // hierarchy has been walked (the loop over the list below).
+      if ((MEDIA && medium) || (CHAINS && hit && (pr.kind & kChainBit) && overhang)) {
+        if (n_cand == lds.cand_cap) {  // list full: settle it first, then come back to the rest of this leaf
+          cur = (((slot << 3) | (leaf_count - k - 1u)) << 1) | 1u;
+          stopped = true;
+          break;
         }
+        stack[(cap + n_cand) * stride] = slot;
+        ++n_cand;
+        hit = false;
       }
+      if (hit) take(t, slot, pr.kind);
     }
+    if (stopped) break;
     cur = pop();  // after the leaf: its hits may already rule the next entries out
   }
+    if (!(MEDIA || CHAINS)) break;
+    // the postponed slots: ConstantMedium::hit, or the flagged record's test again followed by the
+    // reference's box chain.  The closest hit is a minimum over (t, rank): the order of the tests
+    // does not matter.
+    for (uint32_t c = 0; c < n_cand; ++c) {
+      const uint32_t slot = stack[(cap + c) * stride];
+      const DPrim pr = load_prim<false>(sc, lds, slot);
+      double t;
+      bool hit;
+      if (MEDIA && (pr.kind & 15u) == DP_MEDIUM) {
+        hit = medium_t<STATS>(sc, pr, o, d, time, tmin, inf, key, t, st);
+        if (CHAINS && hit && (pr.kind & kChainBit)) hit = reference_chain_passes(sc, (uint32_t)pr.p[3], o, d, tmin);
+      } else {
+        bool overhang = true;
+        Stats unused;  // (the test was counted when the traversal made it)
+        hit = base_prim_t<false>(sc, pr, o, d, dd, time, tmin, inf, t, unused, overhang);
+        hit = hit && reference_chain_passes(sc, (uint32_t)pr.p5, o, d, tmin);
+      }
+      if (hit) take(t, slot, pr.kind);
+    }
+    n_cand = 0u;
+  } while (cur != kNoEntry);
   return best;
 }
 

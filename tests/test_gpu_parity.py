@@ -135,6 +135,40 @@ def test_overhanging_cuboid_sides_follow_the_reference_boxes(gpu_ctx, pipeline):
     assert np.allclose(img, ref, rtol=1e-9, atol=1e-12)  # log10 in the medium: last-place libm differences
 
 
+def many_media_scene(n):
+    """n concentric constant media (thin, so most rays cross all of them) in front of a sphere."""
+    media = "".join(
+        f"ConstantMedium(boundary: Sphere(center: (0, 0, -3), radius: {0.4 + 0.1 * k}, material: Shared(\"grey\")),"
+        f" density: {0.05 + 0.01 * k}, texture: Solid({0.1 + 0.07 * k}, 0.5, {0.9 - 0.07 * k})),\n" for k in range(n))
+    return """Scene(
+  image: (width: 48, height: 36, samples_per_pixel: 2, max_depth: 8),
+  camera: (look_from: (0, 0.5, 2), look_at: (0, 0, -3), vertical_fov: 50, aperture: 0),
+  background: (0.6, 0.7, 1.0),
+  materials: { "grey": Lambertian(albedo: Solid(0.5, 0.5, 0.5)) },
+  objects: [
+    Sphere(center: (0, -1002, -3), radius: 1000, material: Shared("grey")),
+    Sphere(center: (0.3, 0, -3), radius: 0.2, material: Shared("grey")),
+""" + media + "  ]\n)"
+
+
+@pytest.mark.parametrize("pipeline", ["default", "binned"])
+def test_more_media_on_a_ray_than_the_postponed_list_holds(gpu_ctx, pipeline):
+    """Twelve nested media: a traversal sets media aside in a list of eight, so a ray through the
+    middle fills it, has it settled mid-walk and carries on.  Against the reference-topology oracle."""
+    from raytracer_amd import abi
+    scene = HostScene.load_ron_text(many_media_scene(12))
+    gpu_ctx.upload(scene)
+    w, h = 48, 36
+    o = po.Oracle(scene.view_ptr)
+    flags = abi.RT_FLAG_BINNED if pipeline == "binned" else 0
+    img = gpu_ctx.render(gpu_ctx.params(w, h, 0, 4, 8, seed=9, flags=flags), dtype=np.float64)
+    ref = o.render(po.make_params(w, h, 0, 4, 8, 9), po.MODE_ITERATIVE, threads=2)
+    assert np.allclose(img, ref, rtol=1e-9, atol=1e-12)  # log10 in the medium: last-place libm differences
+    ids, t, n = gpu_ctx.first_hit(w, h)  # (the first-hit pass skips media)
+    rid, rt_, rn = o.first_hit(w, h)
+    assert np.array_equal(ids, rid) and np.array_equal(t, rt_) and np.array_equal(n, rn)
+
+
 def test_stats_match_flat_oracle(gpu_ctx, golden_dir):
     """The device walks the flattened BVH exactly as the instrumented CPU traversal does."""
     from raytracer_amd.render import build_bvh
