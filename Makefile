@@ -12,7 +12,7 @@ HOST_SRC := raytracer_amd/host/ron.cpp raytracer_amd/host/loader.cpp raytracer_a
             raytracer_amd/host/jpeg.cpp
 HOST_HDR := raytracer_amd/host/ron.h raytracer_amd/host/host_scene.h raytracer_amd/host/jpeg.h raytracer_amd/csrc/philox.h \
             raytracer_amd/csrc/scene_validate.h include/mi355rt.h
-DEV_SRC := raytracer_amd/csrc/rt_api.hip raytracer_amd/csrc/bvh_build.cpp
+DEV_SRC := raytracer_amd/csrc/rt_api.hip raytracer_amd/csrc/bvh_build.cpp raytracer_amd/csrc/bvh_device.hip
 DEV_HDR := $(wildcard raytracer_amd/csrc/*.h) include/mi355rt.h
 
 # -ffp-contract=off everywhere: the reference is Rust, which never fuses a*b+c.
@@ -32,9 +32,14 @@ $(LIBDIR)/libmi355rt_host.so: $(HOST_SRC) $(HOST_HDR)
 	@mkdir -p $(LIBDIR)
 	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -lz
 
-$(LIBDIR)/libmi355rt.so: $(DEV_SRC) $(DEV_HDR)
+# one object per source, so that `make -j` compiles them side by side and an edit rebuilds one
+DEV_OBJ := $(patsubst raytracer_amd/csrc/%,build/obj/%.o,$(DEV_SRC))
+build/obj/%.o: raytracer_amd/csrc/% $(DEV_HDR)
+	@mkdir -p build/obj
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+$(LIBDIR)/libmi355rt.so: $(DEV_OBJ)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(DEV_SRC)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(DEV_OBJ)
 
 $(LIBDIR)/raytracer: raytracer_amd/host/main.cpp $(LIBDIR)/libmi355rt_host.so $(LIBDIR)/libmi355rt.so
 	$(CXX) $(CXXFLAGS) -o $@ raytracer_amd/host/main.cpp -L$(LIBDIR) -lmi355rt_host -lmi355rt \

@@ -14,6 +14,7 @@
 // were passed" and its box test (src/geom/aabb.rs:35-50) never rejects a true
 // hit.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cfloat>
 #include <cmath>
@@ -161,6 +162,27 @@ bool of_less(double a, double b) {
   return a < b;
 }
 
+unsigned build_threads() {
+  unsigned threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  if (const char* e = getenv("MI355RT_BUILD_THREADS")) threads = (unsigned)std::max(1ul, strtoul(e, nullptr, 10));
+  return threads;
+}
+
+// fn(begin, end) over [0, n) in contiguous pieces, one per thread.
+template <typename F>
+void parallel_for(size_t n, F&& fn) {
+  const unsigned threads = build_threads();
+  if (threads < 2 || n < (1u << 14)) {
+    fn((size_t)0, n);
+    return;
+  }
+  std::vector<std::thread> pool;
+  for (unsigned k = 1; k < threads; ++k)
+    pool.emplace_back([&, k] { fn(n * k / threads, n * (k + 1) / threads); });
+  fn((size_t)0, n / threads);
+  for (std::thread& t : pool) t.join();
+}
+
 // Stable sort of [first, last) on up to `threads` threads: halves sorted side by side, then merged
 // (std::inplace_merge keeps equal elements in order, so the result is std::stable_sort's).
 template <typename It, typename Less>
@@ -222,9 +244,7 @@ void reference_order(const std::vector<Box>& boxes, std::vector<uint32_t>& ids, 
   for (size_t i = 0; i < ids.size(); ++i) keyed[i] = RefOrder::Keyed{0.0, ids[i]};
   const size_t at = out.size();
   out.resize(at + ids.size());
-  unsigned threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-  if (const char* e = getenv("MI355RT_BUILD_THREADS")) threads = std::max(1ul, strtoul(e, nullptr, 10));
-  RefOrder{boxes, out}.run(keyed.data(), keyed.size(), axis, at, threads);
+  RefOrder{boxes, out}.run(keyed.data(), keyed.size(), axis, at, build_threads());
 }
 
 // The box chains of the reference's hierarchy (bvh.rs:33-77): one chain per leaf list, the
@@ -552,6 +572,20 @@ struct Builder {
   }
 };
 
+// Stack entries a traversal of the wide hierarchy can need: a visit pushes at most
+// (children - 1) entries before descending.  Children have larger indices than their parent,
+// so one backward sweep settles it.
+uint32_t stack_need(const std::vector<rt_bvh_node>& out) {
+  std::vector<uint32_t> need(out.size(), 0);
+  for (size_t i = out.size(); i-- > 0;) {
+    if (!(out[i].b & 0x80000000u)) continue;
+    uint32_t k = (out[i].b & 3u) + 1u, deepest = 0;
+    for (uint32_t c = 0; c < k; ++c) deepest = std::max(deepest, need[out[i].a + c]);
+    need[i] = (k - 1u) + deepest;
+  }
+  return out.empty() ? 1u : std::max(1u, need[0]);
+}
+
 // Collapse the binary tree into nodes of up to four children.  Output records are
 // numbered breadth-first and the children of a node are consecutive, so one visit
 // reads up to 128 contiguous bytes and the head of the array is the top of the tree.
@@ -566,7 +600,6 @@ uint32_t collapse_wide(const std::vector<BinNode>& bin, std::vector<rt_bvh_node>
     uint32_t bin_index, record, depth;
   };
   std::vector<Pending> queue{{0u, 0u, 0u}};
-  std::vector<uint32_t> need;  // per record: stack entries its subtree can need (filled backwards)
   depth_out = 0;
   for (size_t q = 0; q < queue.size(); ++q) {
     Pending cur = queue[q];
@@ -602,15 +635,7 @@ uint32_t collapse_wide(const std::vector<BinNode>& bin, std::vector<rt_bvh_node>
       queue.push_back({kids[i], first + i, cur.depth + 1});
     }
   }
-  // children have larger indices than their parent: one backward sweep settles `need`
-  need.assign(out.size(), 0);
-  for (size_t i = out.size(); i-- > 0;) {
-    if (!(out[i].b & 0x80000000u)) continue;
-    uint32_t k = (out[i].b & 3u) + 1u, deepest = 0;
-    for (uint32_t c = 0; c < k; ++c) deepest = std::max(deepest, need[out[i].a + c]);
-    need[i] = (k - 1u) + deepest;
-  }
-  return std::max(1u, need[0]);
+  return stack_need(out);
 }
 
 uint32_t pack_material(uint32_t material) {
@@ -620,7 +645,8 @@ uint32_t pack_ops(uint32_t first, uint32_t count) { return (first & 0x00FFFFFFu)
 
 }  // namespace
 
-std::string flatten_scene(const rt_scene& s, FlatScene& out, int& code) {
+std::string flatten_scene(const rt_scene& s, FlatScene& out, int& code, const WideBuild* wide,
+                          const RefOrderFn* ref_order) {
   // MI355RT_DEBUG: where the time of a flatten goes
   const bool timing = getenv("MI355RT_DEBUG") != nullptr;
   auto clock0 = std::chrono::steady_clock::now();
@@ -646,21 +672,26 @@ std::string flatten_scene(const rt_scene& s, FlatScene& out, int& code) {
   // textures, materials, tables
   out.textures.resize(s.n_textures);
   std::vector<uint8_t> tex_needs_uv(s.n_textures, 0);
-  for (uint32_t i = 0; i < s.n_textures; ++i) {
-    const rt_texture& t = s.textures[i];
-    DTexture d{};
-    d.kind = t.kind;
-    d.a = t.a;
-    d.b = t.b;
-    std::memcpy(d.color, t.color, sizeof d.color);
-    d.scale = t.scale;
-    out.textures[i] = d;
-    // children precede parents (validated), so one forward pass settles the flag
-    if (t.kind == RT_TEX_IMAGE) tex_needs_uv[i] = 1;
-    if (t.kind == RT_TEX_CHECKER) tex_needs_uv[i] = tex_needs_uv[t.a] | tex_needs_uv[t.b];
-  }
+  parallel_for(s.n_textures, [&](size_t t_begin, size_t t_end) {
+    for (size_t i = t_begin; i < t_end; ++i) {
+      const rt_texture& t = s.textures[i];
+      DTexture d{};
+      d.kind = t.kind;
+      d.a = t.a;
+      d.b = t.b;
+      std::memcpy(d.color, t.color, sizeof d.color);
+      d.scale = t.scale;
+      out.textures[i] = d;
+      if (t.kind == RT_TEX_IMAGE) tex_needs_uv[i] = 1;
+    }
+  });
+  // children precede parents (validated), so one forward pass settles a checkerboard's flag
+  for (uint32_t i = 0; i < s.n_textures; ++i)
+    if (s.textures[i].kind == RT_TEX_CHECKER)
+      tex_needs_uv[i] = tex_needs_uv[s.textures[i].a] | tex_needs_uv[s.textures[i].b];
   out.materials.resize(s.n_materials);
-  for (uint32_t i = 0; i < s.n_materials; ++i) {
+  parallel_for(s.n_materials, [&](size_t m_begin, size_t m_end) {
+  for (size_t i = m_begin; i < m_end; ++i) {
     const rt_material& m = s.materials[i];
     DMaterial d{};
     d.kind = m.kind;
@@ -676,6 +707,7 @@ std::string flatten_scene(const rt_scene& s, FlatScene& out, int& code) {
     if (m.kind == RT_MAT_DIELECTRIC) d.albedo[0] = 1.0 / m.param;
     out.materials[i] = d;
   }
+  });
   out.perlin.assign(s.perlin, s.perlin + s.n_perlin);
   out.images.resize(s.n_images);
   for (uint32_t i = 0; i < s.n_images; ++i)
@@ -692,11 +724,34 @@ std::string flatten_scene(const rt_scene& s, FlatScene& out, int& code) {
   lap("materials, ops");
   // reference preference order -> rank of the first primitive of every object
   std::vector<Box> ref_boxes(s.n_objects);
-  for (uint32_t i = 0; i < s.n_objects; ++i) ref_boxes[i] = ref_object_box(s, s.objects[i], t0, t1);
-  std::vector<uint32_t> ids(s.n_objects), order;
-  std::iota(ids.begin(), ids.end(), 0u);
-  order.reserve(s.n_objects);
-  reference_order(ref_boxes, ids, 0, order);
+  parallel_for(s.n_objects, [&](size_t b, size_t e) {
+    for (size_t i = b; i < e; ++i) ref_boxes[i] = ref_object_box(s, s.objects[i], t0, t1);
+  });
+  std::vector<uint32_t> order;
+  if (ref_order && s.n_objects >= 256) {
+    std::vector<double> centres((size_t)3 * s.n_objects);
+    parallel_for(s.n_objects, [&](size_t b, size_t e) {
+      for (size_t i = b; i < e; ++i)
+        for (int a = 0; a < 3; ++a)  // the sort key of bvh.rs:47-53
+          centres[(size_t)a * s.n_objects + i] = (ref_boxes[i].lo[a] + ref_boxes[i].hi[a]) / 2.0;
+    });
+    std::string err = (*ref_order)(centres, s.n_objects, order);
+    if (!err.empty()) {
+      code = RT_ERR_DEVICE;
+      return err;
+    }
+    if (getenv("MI355RT_CHECK_ORDER")) {  // development: the host's sorts must give the same order
+      std::vector<uint32_t> ids(s.n_objects), host_order;
+      std::iota(ids.begin(), ids.end(), 0u);
+      reference_order(ref_boxes, ids, 0, host_order);
+      if (host_order != order) return "device reference order differs from the host's";
+    }
+  } else {
+    std::vector<uint32_t> ids(s.n_objects);
+    std::iota(ids.begin(), ids.end(), 0u);
+    order.reserve(s.n_objects);
+    reference_order(ref_boxes, ids, 0, order);
+  }
   std::vector<uint32_t> rank_base(s.n_objects, 0);
   {
     uint64_t running = 0;
@@ -733,7 +788,9 @@ std::string flatten_scene(const rt_scene& s, FlatScene& out, int& code) {
   uint32_t defer_kinds = 0;
   if (const char* e = getenv("MI355RT_DEFER_KINDS")) defer_kinds = (uint32_t)strtoul(e, nullptr, 0) & 7u;
 
-  auto make_record = [&](const rt_prim& p, uint32_t ops_word, uint32_t object) {
+  // `aux_at`: where a moving sphere's second centre goes in out.aux (slots are made on several
+  // threads, so every object's share of the side arrays is laid out beforehand)
+  auto make_record = [&](const rt_prim& p, uint32_t ops_word, uint32_t object, uint32_t& aux_at, bool& defers) {
     DPrim d{};
     const rt_material& m = s.materials[p.material];
     uint32_t needs_uv = out.materials[p.material].needs_uv ? 1u : 0u;
@@ -754,8 +811,8 @@ std::string flatten_scene(const rt_scene& s, FlatScene& out, int& code) {
       d.p[2] = p.center[2];
       d.p[3] = p.radius;
       d.p[4] = p.time0;
-      d.p5 = (double)out.aux.size();
-      out.aux.push_back(DAux{{p.center1[0], p.center1[1], p.center1[2], p.time1}});
+      d.p5 = (double)aux_at;
+      out.aux[aux_at++] = DAux{{p.center1[0], p.center1[1], p.center1[2], p.time1}};
     } else {
       d.kind = DP_RECT | (p.axis << 4);
       Box b = ref_prim_box(p, 0.0, 0.0);  // AxisAlignedRect::bounding_box, rect.rs:20-34
@@ -775,102 +832,151 @@ std::string flatten_scene(const rt_scene& s, FlatScene& out, int& code) {
     d.kind |= needs_uv << 11;
     if (out.materials[p.material].textured || ((defer_kinds >> (m.kind & 7u)) & 1u)) {
       d.kind |= kDeferBit;
-      out.defers = true;
+      defers = true;
     }
     d.kind |= pack_material(p.material);
     return d;
   };
 
-  // leaf slots in pre-order (object order), then the SAH build permutes them
-  std::vector<DPrim> slots;
-  std::vector<rt_bvh_item> slot_items;
-  std::vector<BuildItem> build_items;
+  // Leaf slots in pre-order (object order), then the build permutes them.  Where each object's
+  // slots, boundary primitives and moving-sphere centres go: one cheap pass; the records and
+  // boxes themselves: in parallel.
+  std::vector<uint32_t> slot_base(s.n_objects + 1, 0), boundary_base(s.n_objects + 1, 0), aux_base(s.n_objects + 1, 0);
   for (uint32_t oi = 0; oi < s.n_objects; ++oi) {
     const rt_object& o = s.objects[oi];
-    auto through_ops = [&](Box b) {
-      for (uint32_t k = o.inner_op_count; k-- > 0;) b = apply_op_box(s.ops[o.inner_first_op + k], b);
-      for (uint32_t k = o.op_count; k-- > 0;) b = apply_op_box(s.ops[o.first_op + k], b);
-      return b;
-    };
-    if (o.is_medium) {
-      out.has_media = true;
-      DPrim d{};
-      d.kind = DP_MEDIUM | ((uint32_t)RT_MAT_ISOTROPIC << 8);
-      d.kind |= (out.materials[o.medium_material].needs_uv ? 1u : 0u) << 11;
-      if (out.materials[o.medium_material].textured) {
-        d.kind |= kDeferBit;
-        out.defers = true;
-      }
-      d.kind |= pack_material(o.medium_material);
-      d.ops = pack_ops(o.first_op, o.op_count);
-      d.material = o.medium_material;
-      d.object = oi;
-      d.p[0] = o.neg_inv_density;
-      d.p[1] = (double)out.boundary.size();
-      d.p[2] = (double)o.prim_count;
-      if (cuboid_overhangs(o)) {  // the medium as a whole answers to its object's chain
-        d.kind |= kChainBit;
-        d.p[3] = (double)chains.chain_of_object[oi];
-      }
-      Box b;
-      for (uint32_t k = 0; k < o.prim_count; ++k) {
-        const rt_prim& p = s.prims[o.first_prim + k];
-        out.boundary.push_back(make_record(p, pack_ops(o.inner_first_op, o.inner_op_count), oi));
-        b.grow(true_prim_box(p, t0, t1));
-      }
-      BuildItem bi;
-      bi.box = through_ops(b);
-      bi.slot = (uint32_t)slots.size();
-      build_items.push_back(bi);
-      slots.push_back(d);
-      slot_items.push_back(rt_bvh_item{oi, kNoPrim, rank_base[oi], 0});
-    } else {
-      for (uint32_t k = 0; k < o.prim_count; ++k) {
-        const rt_prim& p = s.prims[o.first_prim + k];
-        BuildItem bi;
-        bi.box = through_ops(true_prim_box(p, t0, t1));
-        bi.slot = (uint32_t)slots.size();
-        build_items.push_back(bi);
-        slots.push_back(make_record(p, pack_ops(o.first_op, o.op_count), oi));
-        slot_items.push_back(rt_bvh_item{oi, o.first_prim + k, rank_base[oi] + k, 0});
-      }
-    }
+    uint32_t moving = 0;
+    for (uint32_t k = 0; k < o.prim_count; ++k)
+      moving += s.prims[o.first_prim + k].kind == RT_PRIM_MOVING_SPHERE ? 1u : 0u;
+    slot_base[oi + 1] = slot_base[oi] + (o.is_medium ? 1u : o.prim_count);
+    boundary_base[oi + 1] = boundary_base[oi] + (o.is_medium ? o.prim_count : 0u);
+    aux_base[oi + 1] = aux_base[oi] + moving;
+    if (o.is_medium) out.has_media = true;
   }
-  for (BuildItem& bi : build_items)
-    for (int a = 0; a < 3; ++a) {
-      double c = 0.5 * bi.box.lo[a] + 0.5 * bi.box.hi[a];
-      bi.centroid[a] = std::isfinite(c) ? c : 0.0;
+  const size_t n_slots = slot_base[s.n_objects];
+  std::vector<DPrim> slots(n_slots);
+  std::vector<rt_bvh_item> slot_items(n_slots);
+  std::vector<BuildItem> build_items(n_slots);
+  out.boundary.resize(boundary_base[s.n_objects]);
+  out.aux.resize(aux_base[s.n_objects]);
+  std::atomic<bool> any_defers{false};
+  parallel_for(s.n_objects, [&](size_t o_begin, size_t o_end) {
+    bool defers = false;
+    for (size_t oi = o_begin; oi < o_end; ++oi) {
+      const rt_object& o = s.objects[oi];
+      uint32_t aux_at = aux_base[oi];
+      auto through_ops = [&](Box b) {
+        for (uint32_t k = o.inner_op_count; k-- > 0;) b = apply_op_box(s.ops[o.inner_first_op + k], b);
+        for (uint32_t k = o.op_count; k-- > 0;) b = apply_op_box(s.ops[o.first_op + k], b);
+        return b;
+      };
+      auto finish = [&](BuildItem& bi, uint32_t slot) {
+        bi.slot = slot;
+        for (int a = 0; a < 3; ++a) {
+          double c = 0.5 * bi.box.lo[a] + 0.5 * bi.box.hi[a];
+          bi.centroid[a] = std::isfinite(c) ? c : 0.0;
+        }
+      };
+      if (o.is_medium) {
+        DPrim d{};
+        d.kind = DP_MEDIUM | ((uint32_t)RT_MAT_ISOTROPIC << 8);
+        d.kind |= (out.materials[o.medium_material].needs_uv ? 1u : 0u) << 11;
+        if (out.materials[o.medium_material].textured) {
+          d.kind |= kDeferBit;
+          defers = true;
+        }
+        d.kind |= pack_material(o.medium_material);
+        d.ops = pack_ops(o.first_op, o.op_count);
+        d.material = o.medium_material;
+        d.object = (uint32_t)oi;
+        d.p[0] = o.neg_inv_density;
+        d.p[1] = (double)boundary_base[oi];
+        d.p[2] = (double)o.prim_count;
+        if (cuboid_overhangs(o)) {  // the medium as a whole answers to its object's chain
+          d.kind |= kChainBit;
+          d.p[3] = (double)chains.chain_of_object[oi];
+        }
+        Box b;
+        for (uint32_t k = 0; k < o.prim_count; ++k) {
+          const rt_prim& p = s.prims[o.first_prim + k];
+          out.boundary[boundary_base[oi] + k] =
+              make_record(p, pack_ops(o.inner_first_op, o.inner_op_count), (uint32_t)oi, aux_at, defers);
+          b.grow(true_prim_box(p, t0, t1));
+        }
+        const uint32_t slot = slot_base[oi];
+        build_items[slot].box = through_ops(b);
+        finish(build_items[slot], slot);
+        slots[slot] = d;
+        slot_items[slot] = rt_bvh_item{(uint32_t)oi, kNoPrim, rank_base[oi], 0};
+      } else {
+        for (uint32_t k = 0; k < o.prim_count; ++k) {
+          const rt_prim& p = s.prims[o.first_prim + k];
+          const uint32_t slot = slot_base[oi] + k;
+          build_items[slot].box = through_ops(true_prim_box(p, t0, t1));
+          finish(build_items[slot], slot);
+          slots[slot] = make_record(p, pack_ops(o.first_op, o.op_count), (uint32_t)oi, aux_at, defers);
+          slot_items[slot] = rt_bvh_item{(uint32_t)oi, o.first_prim + k, rank_base[oi] + k, 0};
+        }
+      }
     }
+    if (defers) any_defers = true;
+  });
+  out.defers = any_defers;
 
   lap("records, boxes");
   if (!build_items.empty()) {
-    std::vector<BinNode> bin;
-    bin.reserve(build_items.size() * 2);
-    bin.emplace_back();
     std::vector<uint32_t> leaf_order;
-    leaf_order.reserve(build_items.size());
-    Builder b(build_items, bin, leaf_order);
-    if (const char* e = getenv("MI355RT_SAH_MIN_SIDE")) b.min_side = strtod(e, nullptr);
-    if (const char* e = getenv("MI355RT_SAH_BINS")) {
-      long v = strtol(e, nullptr, 10);
-      if (v >= 2 && v <= 128) b.n_bins = (int)v;
+    bool built = false;
+    if (wide && build_items.size() >= 2) {
+      std::vector<rt_bvh_node> leaf_boxes(build_items.size());
+      parallel_for(build_items.size(), [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) {
+          leaf_boxes[i].a = leaf_boxes[i].b = 0;
+          store_box(build_items[i].box, leaf_boxes[i]);
+        }
+      });
+      std::string err = (*wide)(leaf_boxes, out.nodes, leaf_order, out.bvh_depth);
+      if (!err.empty()) {
+        code = RT_ERR_DEVICE;
+        return err;
+      }
+      lap("device build");
+      out.stack_entries = stack_need(out.nodes);
+      lap("stack bound");
+      built = true;
     }
-    if (const char* e = getenv("MI355RT_SAH_SWEEP")) b.sweep_max = strtoul(e, nullptr, 10);
-    if (const char* e = getenv("MI355RT_BUILD_THREADS")) b.parallel = strtoul(e, nullptr, 10) != 1;
-    if (const char* e = getenv("MI355RT_LEAF_ITEMS")) {
-      unsigned long v = strtoul(e, nullptr, 10);
-      if (v >= 1 && v <= kMaxLeafItems) b.max_leaf = (uint32_t)v;
+    if (!built) {
+      std::vector<BinNode> bin;
+      bin.reserve(build_items.size() * 2);
+      bin.emplace_back();
+      leaf_order.reserve(build_items.size());
+      Builder b(build_items, bin, leaf_order);
+      if (const char* e = getenv("MI355RT_SAH_MIN_SIDE")) b.min_side = strtod(e, nullptr);
+      if (const char* e = getenv("MI355RT_SAH_BINS")) {
+        long v = strtol(e, nullptr, 10);
+        if (v >= 2 && v <= 128) b.n_bins = (int)v;
+      }
+      if (const char* e = getenv("MI355RT_SAH_SWEEP")) b.sweep_max = strtoul(e, nullptr, 10);
+      if (const char* e = getenv("MI355RT_BUILD_THREADS")) b.parallel = strtoul(e, nullptr, 10) != 1;
+      if (const char* e = getenv("MI355RT_LEAF_ITEMS")) {
+        unsigned long v = strtoul(e, nullptr, 10);
+        if (v >= 1 && v <= kMaxLeafItems) b.max_leaf = (uint32_t)v;
+      }
+      b.build(0, 0, build_items.size(), 0);
+      lap("SAH build");
+      out.stack_entries = collapse_wide(bin, out.nodes, out.bvh_depth);
+      lap("collapse");
     }
-    b.build(0, 0, build_items.size(), 0);
-    lap("SAH build");
-    out.stack_entries = collapse_wide(bin, out.nodes, out.bvh_depth);
-    lap("collapse");
-    out.prims.reserve(leaf_order.size());
-    for (uint32_t slot : leaf_order) {
-      out.prims.push_back(slots[slot]);
-      out.items.push_back(slot_items[slot]);
-      out.ranks.push_back(slot_items[slot].rank);
-    }
+    out.prims.resize(leaf_order.size());
+    out.items.resize(leaf_order.size());
+    out.ranks.resize(leaf_order.size());
+    parallel_for(leaf_order.size(), [&](size_t b, size_t e) {
+      for (size_t i = b; i < e; ++i) {
+        const uint32_t slot = leaf_order[i];
+        out.prims[i] = slots[slot];
+        out.items[i] = slot_items[slot];
+        out.ranks[i] = slot_items[slot].rank;
+      }
+    });
   }
   lap("leaf order");
   if (out.items.size() >= (1u << 26) || out.nodes.size() >= (1u << 27)) {

@@ -4,6 +4,7 @@
 // would compute them on the host, so the device repeats only per-ray arithmetic.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -123,8 +124,24 @@ struct FlatScene {
   bool defers = false;  // some record carries kDeferBit
 };
 
+// A builder of the wide hierarchy other than the host's: from one float box per leaf slot
+// (rounded outwards; a, b unused) to the records (breadth-first, children consecutive, a leaf
+// record naming one position of leaf_order), the leaf slots in leaf order and the number of
+// levels below the root.  Returns "" or an error message.
+typedef std::function<std::string(const std::vector<rt_bvh_node>& leaf_boxes, std::vector<rt_bvh_node>& records,
+                                  std::vector<uint32_t>& leaf_order, uint32_t& depth)>
+    WideBuild;
+
+// The reference's resolution order of the objects by other means than the host's sorts: from
+// the centres of the objects' reference boxes (x of every object, then y, then z) to the
+// object ids in that order.  Returns "" or an error message.
+typedef std::function<std::string(const std::vector<double>& centres, uint32_t n, std::vector<uint32_t>& order)>
+    RefOrderFn;
+
 // Flatten + build.  Returns "" on success, else an error message; `code`
-// receives the rt_status to report.
-std::string flatten_scene(const rt_scene& scene, FlatScene& out, int& code);
+// receives the rt_status to report.  `wide`: builds the hierarchy instead of the host's SAH
+// build (null: the host's).
+std::string flatten_scene(const rt_scene& scene, FlatScene& out, int& code, const WideBuild* wide = nullptr,
+                          const RefOrderFn* ref_order = nullptr);
 
 }  // namespace rt

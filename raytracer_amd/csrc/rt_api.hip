@@ -30,6 +30,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -42,6 +43,7 @@
 #include <type_traits>
 #include <vector>
 
+#include "bvh_device.h"
 #include "rt_device.h"
 
 using namespace rt;
@@ -871,6 +873,26 @@ to_float_kernel(const double* in, float* out, uint64_t n) {
   if (i < n) out[i] = (float)in[i];
 }
 
+// Records as uploaded -> records as the traversal reads them: the entry code in place of `a`,
+// `b` cleared, and three never-hit records after the last.
+__global__ void __launch_bounds__(kBlock)
+device_records_kernel(rt_bvh_node* records, uint32_t n) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) {
+    records[i].a = make_entry(records[i].a, records[i].b);
+    records[i].b = 0;
+  } else if (i < n + 3u) {
+    rt_bvh_node pad;
+    for (int a = 0; a < 3; ++a) {
+      pad.lo[a] = __int_as_float(0x7F800000);
+      pad.hi[a] = __int_as_float((int)0xFF800000u);
+    }
+    pad.a = 0xFFFFFFFFu;
+    pad.b = 0;
+    records[i] = pad;
+  }
+}
+
 // ------------------------------------------------------------ first hit
 template <bool CHAINS, bool OVERFLOW>
 RT_DEV void first_hit_pixel(const DeviceScene& sc, const LdsScene& lds, const PassInfo& ps,
@@ -1580,9 +1602,20 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* scene) {
   ctx->have_scene = false;
   int code = RT_OK;
   std::string err;
+  // Large scenes get their hierarchy from the device (bvh_device.hip): the host's SAH build of a
+  // million spheres takes longer than rendering them.  MI355RT_DEVICE_BUILD=0 / 1: never / always.
+  bool device_build = scene->n_prims >= (1u << 17);
+  if (const char* e = getenv("MI355RT_DEVICE_BUILD")) device_build = atoi(e) != 0;
+  const WideBuild wide = [&](const std::vector<rt_bvh_node>& leaf_boxes, std::vector<rt_bvh_node>& records,
+                             std::vector<uint32_t>& leaf_order, uint32_t& depth) {
+    return device_build_wide(ctx->stream, leaf_boxes, records, leaf_order, depth);
+  };
+  const RefOrderFn ref_order = [&](const std::vector<double>& centres, uint32_t n, std::vector<uint32_t>& order) {
+    return device_reference_order(ctx->stream, centres, n, order);
+  };
   try {
     auto flat = std::make_shared<FlatScene>();
-    err = flatten_scene(*scene, *flat, code);
+    err = flatten_scene(*scene, *flat, code, device_build ? &wide : nullptr, device_build ? &ref_order : nullptr);
     if (err.empty()) ctx->flat_ptr = flat;
   } catch (const std::exception& e) {
     return fail(ctx, RT_ERR_NOMEM, e.what());
@@ -1605,22 +1638,21 @@ static int upload_flat(rt_ctx* ctx) {
   ctx->have_scene = false;
   const FlatScene& f = ctx->flat();
   int rc;
+  const auto upload_t0 = std::chrono::steady_clock::now();
   {
     // device copy of the records: the traversal entry code in place of `a`, and three
     // never-hit records at the end so that a visit may always read four children
-    std::vector<rt_bvh_node> dn = f.nodes;
-    for (rt_bvh_node& n : dn) {
-      n.a = make_entry(n.a, n.b);
-      n.b = 0;
-    }
-    rt_bvh_node pad{};
-    for (int a = 0; a < 3; ++a) {
-      pad.lo[a] = std::numeric_limits<float>::infinity();
-      pad.hi[a] = -std::numeric_limits<float>::infinity();
-    }
-    pad.a = 0xFFFFFFFFu;
-    for (int k = 0; k < 3; ++k) dn.push_back(pad);
-    if ((rc = upload(ctx, ctx->nodes, dn)) != RT_OK) return rc;
+    ctx->nodes.release();
+    const size_t n_rec = f.nodes.size();
+    RT_HIP(ctx, hipMalloc((void**)&ctx->nodes.p, (n_rec + 3) * sizeof(rt_bvh_node)));
+    ctx->nodes.n = 2 * (n_rec + 3);
+    if (n_rec)
+      RT_HIP(ctx, hipMemcpyAsync(ctx->nodes.p, f.nodes.data(), n_rec * sizeof(rt_bvh_node), hipMemcpyHostToDevice,
+                                 ctx->stream));
+    device_records_kernel<<<blocks_for(n_rec + 3), kBlock, 0, ctx->stream>>>((rt_bvh_node*)ctx->nodes.p,
+                                                                            (uint32_t)n_rec);
+    RT_HIP(ctx, hipGetLastError());
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
   if ((rc = upload(ctx, ctx->prims, f.prims)) != RT_OK) return rc;
   if ((rc = upload(ctx, ctx->ranks, f.ranks)) != RT_OK) return rc;
@@ -1715,6 +1747,9 @@ static int upload_flat(rt_ctx* ctx) {
       ctx->lds.overflow_stride = ctx->lds_trace.overflow_stride = threads;
     }
   }
+  if (getenv("MI355RT_DEBUG"))
+    fprintf(stderr, "mi355rt: copy to the device and LDS plans %.1f ms\n",
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - upload_t0).count());
   if (getenv("MI355RT_DEBUG"))
     fprintf(stderr, "mi355rt: %zu records, %zu leaf slots, stack %u; extend LDS %u B (%u records, %u slots); "
             "trace block %u LDS %u B (%u records, %u slots)\n", f.nodes.size(), f.prims.size(),

@@ -169,6 +169,30 @@ def test_more_media_on_a_ray_than_the_postponed_list_holds(gpu_ctx, pipeline):
     assert np.array_equal(ids, rid) and np.array_equal(t, rt_) and np.array_equal(n, rn)
 
 
+@pytest.mark.parametrize("which", ["cover", "book2", "two_spheres"])
+def test_device_built_hierarchy_gives_the_host_built_results(gpu_ctx, golden_dir, monkeypatch, which):
+    """The hierarchy and the reference's resolution order made on the device (large scenes get
+    them by default) against the host's: the order itself must be the host's (checked inside the
+    upload), first hits and radiance must not depend on which hierarchy is walked."""
+    if which == "cover":
+        scene = HostScene.generate_cover(60, scene_seed=5, width=160, height=90, spp=2, max_depth=12)
+    elif which == "book2":
+        scene, _ = load(golden_dir, "book2")
+    else:
+        scene, _ = load(golden_dir, "material_demo")
+    w, h = scene.width, scene.height
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MI355RT_DEVICE_BUILD", mode)
+        monkeypatch.setenv("MI355RT_CHECK_ORDER", "1")
+        gpu_ctx.upload(scene)
+        ids, t, n = gpu_ctx.first_hit(w, h)
+        img = gpu_ctx.render(gpu_ctx.params(w, h, 0, 2, 12, seed=3), dtype=np.float64)
+        out[mode] = (ids, t, n, img)
+    for a, b in zip(out["0"], out["1"]):
+        assert np.array_equal(a, b)
+
+
 def test_stats_match_flat_oracle(gpu_ctx, golden_dir):
     """The device walks the flattened BVH exactly as the instrumented CPU traversal does."""
     from raytracer_amd.render import build_bvh
