@@ -8,12 +8,10 @@
 // hierarchy over the same leaf boxes returns the same hits.
 //
 //   1. Morton keys (21 bits per axis) of the leaf-box centres, radix-sorted (rocPRIM).
-//   2. Binary radix tree over the sorted keys, one thread per interior node
-//      (Karras, "Maximizing parallelism in the construction of BVHs, octrees, and k-d trees",
-//      HPG 2012); equal keys are told apart by their position.
-//   3. Boxes bottom-up: every leaf walks towards the root, the second thread to arrive at a
-//      node forms the union of its children.
-//   4. Collapse to records of up to four children, breadth-first, the children of a record
+//   2. Binary tree bottom-up by locally-ordered clustering: every cluster, at first the leaves
+//      in key order, looks a few places to either side for the neighbour whose union with it
+//      has the smallest surface; clusters that choose each other merge; repeat until one is left.
+//   3. Collapse to records of up to four children, breadth-first, the children of a record
 //      consecutive: the same rule as the host's collapse_wide (expand the interior child with
 //      the largest box), one level per step with a prefix sum over the frontier.
 // The records come back to the host, which derives the stack bound and uploads them with the
@@ -24,6 +22,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -68,54 +67,6 @@ morton_kernel(const rt_bvh_node* leaves, uint32_t n, Bounds6 cb, uint64_t* keys,
   ids[i] = i;
 }
 
-// Common-prefix length of the keys at sorted positions i and j (-1 outside the array).
-__device__ __forceinline__ int prefix(const uint64_t* keys, int n, int i, int j) {
-  if (j < 0 || j >= n) return -1;
-  const uint64_t a = keys[i], b = keys[j];
-  if (a == b) return 64 + __clz((uint32_t)i ^ (uint32_t)j);
-  return __clzll((long long)(a ^ b));
-}
-
-// Interior node i of the radix tree over n sorted keys: its two children (a leaf is its
-// sorted position with kLeafBit) and their parent links.
-__global__ void __launch_bounds__(kThreads)
-radix_tree_kernel(const uint64_t* keys, int n, uint32_t* left, uint32_t* right, uint32_t* node_parent,
-                  uint32_t* leaf_parent) {
-  const int i = (int)(blockIdx.x * kThreads + threadIdx.x);
-  if (i >= n - 1) return;
-  const int d = prefix(keys, n, i, i + 1) - prefix(keys, n, i, i - 1) >= 0 ? 1 : -1;
-  const int dmin = prefix(keys, n, i, i - d);
-  int lmax = 2;
-  while (prefix(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
-  int l = 0;
-  for (int t = lmax / 2; t >= 1; t /= 2)
-    if (prefix(keys, n, i, i + (l + t) * d) > dmin) l += t;
-  const int j = i + l * d;
-  const int dnode = prefix(keys, n, i, j);
-  int s = 0, t = l;
-  do {
-    t = (t + 1) >> 1;
-    if (prefix(keys, n, i, i + (s + t) * d) > dnode) s += t;
-  } while (t > 1);
-  const int gamma = i + s * d + min(d, 0);
-  const int lo = min(i, j), hi = max(i, j);
-  if (lo == gamma) {
-    left[i] = (uint32_t)gamma | kLeafBit;
-    leaf_parent[gamma] = (uint32_t)i;
-  } else {
-    left[i] = (uint32_t)gamma;
-    node_parent[gamma] = (uint32_t)i;
-  }
-  if (hi == gamma + 1) {
-    right[i] = (uint32_t)(gamma + 1) | kLeafBit;
-    leaf_parent[gamma + 1] = (uint32_t)i;
-  } else {
-    right[i] = (uint32_t)(gamma + 1);
-    node_parent[gamma + 1] = (uint32_t)i;
-  }
-  if (i == 0) node_parent[0] = 0xFFFFFFFFu;
-}
-
 __device__ __forceinline__ Bounds6 box_of(uint32_t ref, const Bounds6* node_box, const rt_bvh_node* leaves,
                                           const uint32_t* ids) {
   if (ref & kLeafBit) {
@@ -131,30 +82,111 @@ __device__ __forceinline__ Bounds6 box_of(uint32_t ref, const Bounds6* node_box,
   return node_box[ref];
 }
 
-// Every leaf climbs; at each node the first arrival stops and the second, which knows both
-// children are done, forms the node's box.  Boxes cross between threads through device-scope
-// fences around the counter.
+// ------------------------------------------------------------ clustering
+// The binary tree bottom-up instead (Meister and Bittner, "Parallel locally-ordered clustering
+// for bounding volume hierarchy construction", TVCG 2018): the clusters, at first the leaves in
+// Morton order, each look a few places to either side for the neighbour whose union with them
+// has the smallest surface; two clusters that choose each other merge into a new node; the
+// array is compacted and the step repeats until one cluster is left.  Merging by surface area
+// instead of by key prefix gives a tree close to a top-down SAH build's (on the million-sphere
+// cover scene 49.5 box tests per ray against 47.1 for the host's sweep build, 55.0 for a radix tree
+// over the same keys with boxes fitted afterwards, and the host build's render time).
+const int kMaxRadius = 32;
+
 __global__ void __launch_bounds__(kThreads)
-refit_kernel(const rt_bvh_node* leaves, const uint32_t* ids, int n, const uint32_t* left, const uint32_t* right,
-             const uint32_t* node_parent, const uint32_t* leaf_parent, uint32_t* arrived, Bounds6* node_box) {
-  const int j = (int)(blockIdx.x * kThreads + threadIdx.x);
-  if (j >= n) return;
-  uint32_t cur = leaf_parent[j];
-  while (cur != 0xFFFFFFFFu) {
-    __threadfence();
-    if (atomicAdd(&arrived[cur], 1u) == 0u) return;
-    __threadfence();
-    const Bounds6 a = box_of(left[cur], node_box, leaves, ids);
-    const Bounds6 b = box_of(right[cur], node_box, leaves, ids);
-    Bounds6 u;
+leaf_clusters_kernel(const rt_bvh_node* leaves, const uint32_t* ids, uint32_t n, uint32_t* ref, Bounds6* box) {
+  const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n) return;
+  ref[i] = i | kLeafBit;
+  const rt_bvh_node b = leaves[ids[i]];
+  Bounds6 r;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      u.lo[k] = fminf(a.lo[k], b.lo[k]);
-      u.hi[k] = fmaxf(a.hi[k], b.hi[k]);
-    }
-    node_box[cur] = u;  // (the parent's second arrival reads it after the fence pair)
-    cur = node_parent[cur];
+  for (int a = 0; a < 3; ++a) {
+    r.lo[a] = b.lo[a];
+    r.hi[a] = b.hi[a];
   }
+  box[i] = r;
+}
+
+__device__ __forceinline__ float union_area(const Bounds6& a, const Bounds6& b) {
+  const float x = fmaxf(a.hi[0], b.hi[0]) - fminf(a.lo[0], b.lo[0]);
+  const float y = fmaxf(a.hi[1], b.hi[1]) - fminf(a.lo[1], b.lo[1]);
+  const float z = fmaxf(a.hi[2], b.hi[2]) - fminf(a.lo[2], b.lo[2]);
+  return x * y + y * z + z * x;
+}
+
+// nearest[i]: the position within `radius` of i whose union with cluster i is smallest (the
+// lower position among equals).  A block works on its 256 clusters from a copy in LDS that
+// reaches `radius` beyond both ends.
+__global__ void __launch_bounds__(kThreads)
+nearest_kernel(const Bounds6* box, uint32_t n, int radius, uint32_t* nearest) {
+  __shared__ Bounds6 s_box[kThreads + 2 * kMaxRadius];
+  const int first = (int)(blockIdx.x * kThreads) - radius;
+  for (int k = (int)threadIdx.x; k < kThreads + 2 * radius; k += kThreads) {
+    const int g = first + k;
+    if (g >= 0 && g < (int)n) s_box[k] = box[g];
+  }
+  __syncthreads();
+  const int i = (int)(blockIdx.x * kThreads + threadIdx.x);
+  if (i >= (int)n) return;
+  const Bounds6 mine = s_box[threadIdx.x + radius];
+  float best = __int_as_float(0x7F800000);
+  int best_j = -1;
+  for (int dj = -radius; dj <= radius; ++dj) {
+    const int j = i + dj;
+    if (dj == 0 || j < 0 || j >= (int)n) continue;
+    float a = union_area(mine, s_box[(int)threadIdx.x + radius + dj]);
+    if (!(a < 3.0e38f)) a = 3.0e38f;  // (boxes that never cull have no finite surface: any partner will do)
+    if (a < best) {
+      best = a;
+      best_j = j;
+    }
+  }
+  nearest[i] = (uint32_t)best_j;
+}
+
+// Mutual pairs merge: the lower position keeps the new node, the upper one leaves the array.
+__global__ void __launch_bounds__(kThreads)
+merge_kernel(const uint32_t* ref, const Bounds6* box, const uint32_t* nearest, uint32_t n, uint32_t* node_count,
+             uint32_t* left, uint32_t* right, Bounds6* node_box, uint32_t* out_ref, Bounds6* out_box,
+             uint32_t* keep) {
+  const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t j = nearest[i];
+  const bool mutual = j < n && nearest[j] == i;
+  if (!mutual) {
+    out_ref[i] = ref[i];
+    out_box[i] = box[i];
+    keep[i] = 1u;
+    return;
+  }
+  if (i > j) {
+    keep[i] = 0u;
+    return;
+  }
+  const Bounds6 a = box[i], b = box[j];
+  Bounds6 u;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    u.lo[k] = fminf(a.lo[k], b.lo[k]);
+    u.hi[k] = fmaxf(a.hi[k], b.hi[k]);
+  }
+  const uint32_t node = atomicAdd(node_count, 1u);
+  left[node] = ref[i];
+  right[node] = ref[j];
+  node_box[node] = u;
+  out_ref[i] = node;
+  out_box[i] = u;
+  keep[i] = 1u;
+}
+
+__global__ void __launch_bounds__(kThreads)
+compact_kernel(const uint32_t* in_ref, const Bounds6* in_box, const uint32_t* keep, const uint32_t* offset,
+               uint32_t n, uint32_t* ref, Bounds6* box) {
+  const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n || !keep[i]) return;
+  ref[offset[i]] = in_ref[i];
+  box[offset[i]] = in_box[i];
 }
 
 __device__ __forceinline__ float half_area(const Bounds6& b) {
@@ -231,11 +263,11 @@ emit_level_kernel(const uint32_t* front_ref, const uint32_t* front_rec, uint32_t
   }
 }
 
-__global__ void root_record_kernel(const Bounds6* node_box, rt_bvh_node* records) {
+__global__ void root_record_kernel(const Bounds6* node_box, uint32_t root, rt_bvh_node* records) {
   rt_bvh_node r;
   for (int a = 0; a < 3; ++a) {
-    r.lo[a] = node_box[0].lo[a];
-    r.hi[a] = node_box[0].hi[a];
+    r.lo[a] = node_box[root].lo[a];
+    r.hi[a] = node_box[root].hi[a];
   }
   r.a = 0;
   r.b = 0;
@@ -304,7 +336,7 @@ std::string device_build_wide(hipStream_t stream, const std::vector<rt_bvh_node>
   rt_bvh_node *d_leaves = nullptr, *d_records = nullptr;
   uint64_t *d_keys = nullptr, *d_keys_sorted = nullptr;
   uint32_t *d_ids = nullptr, *d_ids_sorted = nullptr, *d_left = nullptr, *d_right = nullptr;
-  uint32_t *d_node_parent = nullptr, *d_leaf_parent = nullptr, *d_arrived = nullptr;
+  uint32_t* d_arrived = nullptr;  // nodes made so far
   Bounds6* d_node_box = nullptr;
   const size_t max_records = 2 * n + 4;
   mem.plan(&d_leaves, n);
@@ -315,9 +347,7 @@ std::string device_build_wide(hipStream_t stream, const std::vector<rt_bvh_node>
   mem.plan(&d_ids_sorted, n);
   mem.plan(&d_left, n);
   mem.plan(&d_right, n);
-  mem.plan(&d_node_parent, n);
-  mem.plan(&d_leaf_parent, n);
-  mem.plan(&d_arrived, n);
+  mem.plan(&d_arrived, 1);
   mem.plan(&d_node_box, n);
   // frontier buffers, ping-pong: a level has at most n entries of each kind
   uint32_t *d_ref[2] = {nullptr, nullptr}, *d_rec[2] = {nullptr, nullptr}, *d_kids = nullptr, *d_count = nullptr,
@@ -326,6 +356,15 @@ std::string device_build_wide(hipStream_t stream, const std::vector<rt_bvh_node>
     mem.plan(&d_ref[k], max_records);
     mem.plan(&d_rec[k], max_records);
   }
+  uint32_t *d_cref[2] = {nullptr, nullptr}, *d_mref = nullptr, *d_nearest = nullptr;
+  Bounds6 *d_cbox[2] = {nullptr, nullptr}, *d_mbox = nullptr;
+  for (int k = 0; k < 2; ++k) {
+    mem.plan(&d_cref[k], n);
+    mem.plan(&d_cbox[k], n);
+  }
+  mem.plan(&d_mref, n);
+  mem.plan(&d_mbox, n);
+  mem.plan(&d_nearest, n);
   mem.plan(&d_kids, 4 * max_records);
   mem.plan(&d_count, max_records + 1);
   mem.plan(&d_offset, max_records + 1);
@@ -340,13 +379,37 @@ std::string device_build_wide(hipStream_t stream, const std::vector<rt_bvh_node>
   LB_HIP(hipMemcpyAsync(d_leaves, leaf_boxes.data(), n * sizeof(rt_bvh_node), hipMemcpyHostToDevice, stream));
   morton_kernel<<<blocks(n), kThreads, 0, stream>>>(d_leaves, (uint32_t)n, cb, d_keys, d_ids);
   LB_HIP(rocprim::radix_sort_pairs(d_tmp, sort_bytes, d_keys, d_keys_sorted, d_ids, d_ids_sorted, n, 0, 63, stream));
-  radix_tree_kernel<<<blocks(n - 1), kThreads, 0, stream>>>(d_keys_sorted, (int)n, d_left, d_right, d_node_parent,
-                                                            d_leaf_parent);
-  LB_HIP(hipMemsetAsync(d_arrived, 0, n * sizeof(uint32_t), stream));
-  refit_kernel<<<blocks(n), kThreads, 0, stream>>>(d_leaves, d_ids_sorted, (int)n, d_left, d_right, d_node_parent,
-                                                   d_leaf_parent, d_arrived, d_node_box);
-  root_record_kernel<<<1, 1, 0, stream>>>(d_node_box, d_records);
-  const uint32_t root_ref = 0u, root_rec = 0u;
+  uint32_t root = 0u;
+  {
+    // clustering: the cluster arrays ping-pong between (ref, box) pairs; d_arrived counts the nodes
+    uint32_t n_cur = (uint32_t)n;
+    LB_HIP(hipMemsetAsync(d_arrived, 0, sizeof(uint32_t), stream));
+    leaf_clusters_kernel<<<blocks(n), kThreads, 0, stream>>>(d_leaves, d_ids_sorted, n_cur, d_cref[0], d_cbox[0]);
+    int cc = 0;
+    uint32_t steps = 0;
+    int radius = 4;  // (measured on the cover scene: 3-4 gives the host build's box tests per ray, 10 and more 10-20 % more)
+    if (const char* e = getenv("MI355RT_CLUSTER_RADIUS")) radius = std::min(std::max(atoi(e), 1), kMaxRadius);
+    while (n_cur > 1) {
+      nearest_kernel<<<blocks(n_cur), kThreads, 0, stream>>>(d_cbox[cc], n_cur, radius, d_nearest);
+      merge_kernel<<<blocks(n_cur), kThreads, 0, stream>>>(d_cref[cc], d_cbox[cc], d_nearest, n_cur, d_arrived, d_left,
+                                                           d_right, d_node_box, d_mref, d_mbox, d_count);
+      LB_HIP(hipMemsetAsync(d_count + n_cur, 0, sizeof(uint32_t), stream));
+      LB_HIP(rocprim::exclusive_scan(d_tmp, scan_bytes, d_count, d_offset, 0u, (size_t)n_cur + 1,
+                                     rocprim::plus<uint32_t>(), stream));
+      compact_kernel<<<blocks(n_cur), kThreads, 0, stream>>>(d_mref, d_mbox, d_count, d_offset, n_cur, d_cref[cc ^ 1],
+                                                             d_cbox[cc ^ 1]);
+      uint32_t left_over = 0;
+      LB_HIP(hipMemcpyAsync(&left_over, d_offset + n_cur, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+      LB_HIP(hipStreamSynchronize(stream));
+      if (left_over == 0 || left_over >= n_cur) return "device build: clustering made no progress";
+      n_cur = left_over;
+      cc ^= 1;
+      if (++steps > 100000u) return "device build: clustering did not end";
+    }
+    root = (uint32_t)n - 2u;  // the last merge made the last node
+  }
+  root_record_kernel<<<1, 1, 0, stream>>>(d_node_box, root, d_records);
+  const uint32_t root_ref = root, root_rec = 0u;
   LB_HIP(hipMemcpyAsync(d_ref[0], &root_ref, sizeof(uint32_t), hipMemcpyHostToDevice, stream));
   LB_HIP(hipMemcpyAsync(d_rec[0], &root_rec, sizeof(uint32_t), hipMemcpyHostToDevice, stream));
   uint32_t n_front = 1, n_records = 1, level = 0;
