@@ -306,6 +306,11 @@ enum {
  * `let Scene{..} = loader.load()?` handing the world to the render closure
  * (src/main.rs:50-55,77-80). */
 int rt_create(const rt_config* cfg, rt_ctx** out);
+/* Copies the scene and builds the acceleration structure: on the host below 2^17 primitives, on
+ * the device above (environment MI355RT_DEVICE_BUILD=0 / 1 forces either).  What a render
+ * returns does not depend on where or how the hierarchy was built: the reference's own BVH
+ * (src/hittable/bvh.rs:33-77) only decides between hits at exactly the same t, and that order
+ * is carried by per-slot ranks. */
 int rt_upload_scene(rt_ctx* ctx, const rt_scene* scene);
 
 /* Replaces the render closure src/main.rs:82-101 minus the 8-bit resolve:
