@@ -7,6 +7,7 @@
 #include <fstream>
 #include <sstream>
 #include <stdexcept>
+#include <memory>
 #include <string>
 
 #include "../csrc/scene_validate.h"
@@ -71,10 +72,19 @@ template <typename T>
 bool write_vec(gzFile f, const std::vector<T>& v) {
   return v.empty() || gz_write(f, v.data(), v.size() * sizeof(T));
 }
+// n records in pieces of at most 16 MiB, the vector growing as they arrive: a count that the
+// file does not back (a corrupted or crafted header) ends in "truncated", not in an allocation
+// of whatever the header claims.
 template <typename T>
 bool read_vec(gzFile f, std::vector<T>& v, size_t n) {
-  v.resize(n);
-  return n == 0 || gz_read(f, v.data(), n * sizeof(T));
+  const size_t piece = std::max<size_t>(1, ((size_t)16 << 20) / sizeof(T));
+  v.clear();
+  while (v.size() < n) {
+    const size_t at = v.size(), take = std::min(piece, n - at);
+    v.resize(at + take);
+    if (!gz_read(f, v.data() + at, take * sizeof(T))) return false;
+  }
+  return true;
 }
 
 }  // namespace
@@ -172,30 +182,31 @@ int rt_host_load_frozen(const char* path, rt_host_scene** out) {
       h.sizeof_texture != sizeof(rt_texture) || h.sizeof_perlin != sizeof(rt_perlin) ||
       h.sizeof_image != sizeof(rt_image))
     return set_error(RT_ERR_PARSE, std::string(path) + ": record sizes do not match this build");
-  auto* s = new rt_host_scene();
-  s->camera_desc = h.camera_desc;
-  s->view.camera = h.camera;
-  std::memcpy(s->view.background, h.background, sizeof h.background);
-  s->view.width = h.width;
-  s->view.height = h.height;
-  s->view.samples_per_pixel = h.samples_per_pixel;
-  s->view.max_depth = h.max_depth;
-  bool ok = read_vec(f, s->objects, h.n_objects) && read_vec(f, s->prims, h.n_prims) &&
-            read_vec(f, s->ops, h.n_ops) && read_vec(f, s->materials, h.n_materials) &&
-            read_vec(f, s->textures, h.n_textures) && read_vec(f, s->perlin, h.n_perlin) &&
-            read_vec(f, s->images, h.n_images) && read_vec(f, s->texels, h.n_texel_bytes);
-  if (!ok) {
-    delete s;
-    return set_error(RT_ERR_IO, std::string(path) + ": truncated frozen scene");
+  // (nothing thrown here may cross the C boundary)
+  try {
+    std::unique_ptr<rt_host_scene> s(new rt_host_scene());
+    s->camera_desc = h.camera_desc;
+    s->view.camera = h.camera;
+    std::memcpy(s->view.background, h.background, sizeof h.background);
+    s->view.width = h.width;
+    s->view.height = h.height;
+    s->view.samples_per_pixel = h.samples_per_pixel;
+    s->view.max_depth = h.max_depth;
+    bool ok = read_vec(f, s->objects, h.n_objects) && read_vec(f, s->prims, h.n_prims) &&
+              read_vec(f, s->ops, h.n_ops) && read_vec(f, s->materials, h.n_materials) &&
+              read_vec(f, s->textures, h.n_textures) && read_vec(f, s->perlin, h.n_perlin) &&
+              read_vec(f, s->images, h.n_images) && read_vec(f, s->texels, h.n_texel_bytes);
+    if (!ok) return set_error(RT_ERR_IO, std::string(path) + ": truncated frozen scene");
+    s->refresh_view();
+    std::string bad = rt::validate_scene(s->view);
+    if (!bad.empty()) return set_error(RT_ERR_PARSE, std::string(path) + ": invalid " + bad);
+    *out = s.release();
+    return RT_OK;
+  } catch (const std::bad_alloc&) {
+    return set_error(RT_ERR_NOMEM, std::string(path) + ": out of memory");
+  } catch (const std::exception& e) {
+    return set_error(RT_ERR_PARSE, std::string(path) + ": " + e.what());
   }
-  s->refresh_view();
-  std::string bad = rt::validate_scene(s->view);
-  if (!bad.empty()) {
-    delete s;
-    return set_error(RT_ERR_PARSE, std::string(path) + ": invalid " + bad);
-  }
-  *out = s;
-  return RT_OK;
 }
 
 int rt_host_generate_cover(uint32_t half_extent, uint64_t scene_seed, uint32_t width,

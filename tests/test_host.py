@@ -259,3 +259,30 @@ def test_image_texture_loads_the_jpeg_itself(tmp_path):
     assert v.n_images == 1 and v.images[0].width == 64 and v.images[0].height == 32
     texels = np.ctypeslib.as_array(v.texels, shape=(v.n_texel_bytes,))
     assert np.array_equal(texels.reshape(32, 64, 3), decode_jpeg(data))
+
+
+def test_frozen_scene_with_a_corrupted_header_is_refused_cleanly(tmp_path):
+    """Counts in the header that the file does not back (0xFFFFFFFF in any header word) must end in an
+    error code: no exception across the C boundary, no allocation of what the header claims."""
+    import gzip
+    import resource
+    from raytracer_amd.scene import HostScene
+    golden = os.path.join(os.path.dirname(__file__), "golden", "material_demo.rtscene")
+    raw = gzip.open(golden, "rb").read()
+    soft, hard = resource.getrlimit(resource.RLIMIT_AS)
+    refused = loaded = 0
+    try:
+        resource.setrlimit(resource.RLIMIT_AS, (8 << 30, hard))  # a 4 G-record allocation would fail loudly
+        for at in range(0, min(len(raw) - 4, 800), 4):
+            bad = bytearray(raw)
+            bad[at:at + 4] = b"\xff\xff\xff\xff"
+            path = tmp_path / "bad.rtscene"
+            path.write_bytes(bytes(bad))  # (plain bytes: the reader takes uncompressed files too)
+            try:
+                HostScene.load_frozen(path).close()
+                loaded += 1
+            except RuntimeError:
+                refused += 1
+    finally:
+        resource.setrlimit(resource.RLIMIT_AS, (soft, hard))
+    assert refused >= 8 and refused + loaded == len(range(0, min(len(raw) - 4, 800), 4))
