@@ -294,6 +294,8 @@ extend_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32
   if (blockIdx.x * kBlock >= n_live) return;  // nothing for this workgroup: skip the staging
   if (threadIdx.x < kBins) s_bin_count[threadIdx.x] = 0;
   const LdsScene lds = lds_stage(sc, lay, smem, threadIdx.x, kBlock);  // ends with a barrier
+  sc.ops_lds_offset = lds.ops_offset;
+  sc.n_ops_lds = lay.n_ops;
   // whole workgroups iterate together so that every lane reaches the ballots and barriers
   for (uint32_t base = blockIdx.x * kBlock; base < n_live; base += stride) {
     uint32_t i = base + threadIdx.x;
@@ -611,6 +613,8 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
   const uint32_t n_live = live.total();
   if (blockIdx.x * (uint32_t)BLOCK >= n_live) return;
   const LdsScene lds = lds_stage(sc, lay, smem, threadIdx.x, BLOCK);  // the only workgroup barrier
+  sc.ops_lds_offset = lds.ops_offset;
+  sc.n_ops_lds = lay.n_ops;
   uint32_t* stage = s_next + (threadIdx.x / 64u) * kWaveStage;
   uint32_t* defer_stage = s_defer + (DEFER ? (threadIdx.x / 64u) * kDeferStage : 0u);
   uint32_t n_staged = 0, n_deferred = 0;  // wave-uniform
@@ -904,6 +908,8 @@ first_hit_kernel(DeviceScene sc, LdsLayout lay, PassInfo ps, uint32_t* id, doubl
                  double* normal) {
   extern __shared__ __align__(16) char smem[];
   const LdsScene lds = lds_stage(sc, lay, smem, threadIdx.x, kBlock);
+  sc.ops_lds_offset = lds.ops_offset;
+  sc.n_ops_lds = lay.n_ops;
   for (uint32_t local = blockIdx.x * kBlock + threadIdx.x; local < ps.n_pixels;
        local += gridDim.x * kBlock)
     first_hit_pixel<CHAINS, OVERFLOW>(sc, lds, ps, local, id, t_out, normal);
@@ -1189,7 +1195,9 @@ LdsLayout plan_lds(const FlatScene& f, uint32_t block, uint32_t budget, uint32_t
   uint32_t flagged = 0;
   for (const DPrim& pr : f.prims) flagged += ((pr.kind & 15u) == DP_MEDIUM || (pr.kind & kChainBit)) ? 1u : 0u;
   l.cand_rows = std::min(flagged, 8u);
-  uint32_t used = (l.stack_depth + l.cand_rows) * block * (uint32_t)sizeof(uint32_t);
+  // scenes with a few dozen wrapper ops keep them in LDS (cornell: four)
+  l.n_ops = f.ops.size() <= 64 ? (uint32_t)f.ops.size() : 0u;
+  uint32_t used = (l.stack_depth + l.cand_rows) * block * (uint32_t)sizeof(uint32_t) + l.n_ops * 32u;
   budget = std::max(budget, used + 4096u);  // leave room for a few records
   uint32_t room = budget - used;
   // (+3: the never-hit records that end the device copy, so the last group stays in LDS)
@@ -1686,6 +1694,8 @@ static int upload_flat(rt_ctx* ctx) {
   for (const DMaterial& m : f.materials)
     if (m.kind == RT_MAT_DIFFUSE_LIGHT) ds.has_lights = 1u;
   ds.root_code = f.nodes.empty() ? 1u : make_entry(f.nodes[0].a, f.nodes[0].b);
+  ds.ops_lds_offset = 0u;
+  ds.n_ops_lds = 0u;
   ds.cam = f.camera;
   std::memcpy(ds.bg, f.background, sizeof ds.bg);
   // LDS plans.  extend/first_hit: 256-thread workgroups, four to a CU next to their

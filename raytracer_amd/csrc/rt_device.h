@@ -34,6 +34,9 @@ struct DeviceScene {
   uint32_t has_media;
   uint32_t has_lights;  // some material is a DiffuseLight (else a path's L stays 0 until its last event)
   uint32_t root_code;  // traversal entry code of the root record
+  // wrapper ops [0, n_ops_lds) have a copy in the workgroup's dynamic LDS, ops_lds_offset bytes in
+  // (set by a kernel after it staged them; 0 ops for kernels that stage nothing)
+  uint32_t ops_lds_offset, n_ops_lds;
   rt_camera cam;
   double bg[3];
 };
@@ -150,14 +153,43 @@ RT_DEV void stat(Stats& s, int which) {
 RT_DEV uint32_t ops_first(uint32_t w) { return w & 0x00FFFFFFu; }
 RT_DEV uint32_t ops_count(uint32_t w) { return w >> 24; }
 
+// The pointers carry the LDS address space: a generic pointer that may be LDS or
+// global turns every access into a flat instruction, several times slower to
+// return than a ds_read.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+
+// Wrapper op `index`: from the workgroup's LDS copy when the scene's ops were staged there
+// (scenes with a few dozen ops: a leaf test behind two wrappers otherwise waits for two
+// dependent reads of global memory inside the traversal loop; cornell 113.2 -> 103.9 ms per
+// 32 spp), else from global memory.
+RT_DEV DOp load_op(const DeviceScene& sc, uint32_t index) {
+  union {
+    f32x4 q[2];
+    DOp op;
+  } u;
+  if (index < sc.n_ops_lds) {
+    extern __shared__ __align__(16) char rt_dynamic_lds[];
+    const lds_f32x4* l = (const lds_f32x4*)(rt_dynamic_lds + sc.ops_lds_offset) + 2u * index;
+    u.q[0] = l[0];
+    u.q[1] = l[1];
+  } else {
+    const f32x4* g = (const f32x4*)(sc.ops + index);
+    u.q[0] = g[0];
+    u.q[1] = g[1];
+  }
+  return u.op;
+}
+
 // Forward (world -> innermost frame) transform of a ray through wrapper ops,
 // outermost first: Translate::hit instance.rs:13, RotateY::hit instance.rs:52-61.
 template <bool STATS>
 RT_DEV void ops_forward(const DeviceScene& sc, uint32_t ops_word, uint32_t upto, V3& o, V3& d,
                         Stats& st) {
-  const DOp* ops = sc.ops + ops_first(ops_word);
+  const uint32_t first = ops_first(ops_word);
   for (uint32_t k = 0; k < upto; ++k) {
-    const DOp op = ops[k];
+    const DOp op = load_op(sc, first + k);
     if (op.kind == RT_OP_TRANSLATE) {
       stat<STATS>(st, RT_STAT_OP_TRANSLATE);
       o = vsub(o, v3(op.a));
@@ -177,10 +209,11 @@ RT_DEV void ops_forward(const DeviceScene& sc, uint32_t ops_word, uint32_t upto,
 
 // Direction of the ray as seen by wrapper `level` (after ops [0, level]).
 RT_DEV V3 ops_direction(const DeviceScene& sc, uint32_t ops_word, uint32_t level, V3 d) {
-  const DOp* ops = sc.ops + ops_first(ops_word);
+  const uint32_t first = ops_first(ops_word);
   for (uint32_t k = 0; k <= level; ++k) {
-    if (ops[k].kind == RT_OP_ROTATE_Y) {
-      double s = ops[k].a[0], c = ops[k].a[1];
+    const DOp op = load_op(sc, first + k);
+    if (op.kind == RT_OP_ROTATE_Y) {
+      double s = op.a[0], c = op.a[1];
       V3 nd = d;
       nd.x = c * d.x - s * d.z;
       nd.z = s * d.x + c * d.z;
@@ -204,9 +237,9 @@ RT_DEV void set_face_normal(Record& r, V3 dir, V3 outward) {  // mod.rs:65-68
 // Backward pass of the wrappers over a record, innermost first
 // (Translate instance.rs:14-18, RotateY instance.rs:63-82 with its x-for-z slip kept).
 RT_DEV void ops_backward(const DeviceScene& sc, uint32_t ops_word, V3 world_dir, Record& r) {
-  const DOp* ops = sc.ops + ops_first(ops_word);
+  const uint32_t first = ops_first(ops_word);
   for (uint32_t k = ops_count(ops_word); k-- > 0;) {
-    const DOp op = ops[k];
+    const DOp op = load_op(sc, first + k);
     V3 dir = ops_direction(sc, ops_word, k, world_dir);
     if (op.kind == RT_OP_TRANSLATE) {
       r.p = vadd(r.p, v3(op.a));
@@ -458,6 +491,7 @@ struct LdsLayout {
   uint32_t n_prims;      // leaf slots [0, n_prims) are in LDS
   uint32_t stack_depth;  // stack entries per lane held in LDS
   uint32_t cand_rows;    // rows after the stack: leaf slots whose test waits for the end of the traversal
+  uint32_t n_ops;        // wrapper ops [0, n_ops) are in LDS, between the leaf slots and the stack
   uint32_t bytes;        // total dynamic LDS bytes per workgroup
   uint32_t entry_bits;   // bits of a traversal entry code (see entry_code_bits)
   // Hierarchies whose worst-case stack need exceeds stack_depth: entries from index
@@ -466,12 +500,6 @@ struct LdsLayout {
   uint32_t* overflow;
   uint32_t overflow_stride;  // threads the overflow area was sized for (a launch has no more)
 };
-// The pointers carry the LDS address space: a generic pointer that may be LDS or
-// global turns every access into a flat instruction, several times slower to
-// return than a ds_read.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
-typedef __attribute__((address_space(3))) uint32_t lds_u32;
 struct LdsScene {
   const lds_f32x4* nodes;
   const lds_f32x4* prims;  // the first 3 x 16 bytes of each DPrim
@@ -479,6 +507,7 @@ struct LdsScene {
   uint32_t n_nodes, n_prims, stack_stride, entry_bits;
   uint32_t stack_cap;      // entries of the column that exist in LDS
   uint32_t cand_cap;       // rows [stack_cap, stack_cap + cand_cap) of the column: postponed leaf slots
+  uint32_t ops_offset;     // bytes from the start of the dynamic LDS to the staged wrapper ops
   uint32_t* overflow;      // this lane's column of the global overflow area, or null (uniform)
   uint32_t overflow_stride;
 };
@@ -489,11 +518,14 @@ RT_DEV LdsScene lds_stage(const DeviceScene& sc, const LdsLayout& lay, char* sme
                           uint32_t block) {
   lds_f32x4* nodes = (lds_f32x4*)smem;
   lds_f32x4* prims = nodes + 2u * lay.n_nodes;
-  lds_u32* stack = (lds_u32*)(prims + 3u * lay.n_prims);
+  lds_f32x4* ops = prims + 3u * lay.n_prims;
+  lds_u32* stack = (lds_u32*)(ops + 2u * lay.n_ops);
   const f32x4* gn = (const f32x4*)sc.nodes;
   const f32x4* gp = (const f32x4*)sc.prims;
+  const f32x4* go = (const f32x4*)sc.ops;
   for (uint32_t i = tid; i < 2u * lay.n_nodes; i += block) nodes[i] = gn[i];
   for (uint32_t i = tid; i < 3u * lay.n_prims; i += block) prims[i] = gp[4u * (i / 3u) + i % 3u];
+  for (uint32_t i = tid; i < 2u * lay.n_ops; i += block) ops[i] = go[i];
   __syncthreads();
   LdsScene l;
   l.nodes = nodes;
@@ -507,6 +539,7 @@ RT_DEV LdsScene lds_stage(const DeviceScene& sc, const LdsLayout& lay, char* sme
   l.cand_cap = lay.cand_rows;
   l.overflow = lay.overflow ? lay.overflow + (blockIdx.x * block + tid) : nullptr;
   l.overflow_stride = lay.overflow_stride;
+  l.ops_offset = 32u * lay.n_nodes + kPrimHotBytes * lay.n_prims;
   return l;
 }
 
