@@ -935,14 +935,16 @@ std::string flatten_scene(const rt_scene& s, FlatScene& out, int& code, const Wi
         }
       });
       std::string err = (*wide)(leaf_boxes, out.nodes, leaf_order, out.bvh_depth);
-      if (!err.empty()) {
-        code = RT_ERR_DEVICE;
-        return err;
+      if (err.empty()) {
+        lap("device build");
+        out.stack_entries = stack_need(out.nodes);
+        lap("stack bound");
+        built = true;
+      } else {  // the host's build serves every scene
+        if (timing) fprintf(stderr, "mi355rt: %s; building on the host\n", err.c_str());
+        out.nodes.clear();
+        leaf_order.clear();
       }
-      lap("device build");
-      out.stack_entries = stack_need(out.nodes);
-      lap("stack bound");
-      built = true;
     }
     if (!built) {
       std::vector<BinNode> bin;

@@ -115,8 +115,7 @@ __device__ __forceinline__ float union_area(const Bounds6& a, const Bounds6& b) 
   return x * y + y * z + z * x;
 }
 
-// nearest[i]: the position within `radius` of i whose union with cluster i is smallest (the
-// lower position among equals).  A block works on its 256 clusters from a copy in LDS that
+// nearest[i]: the position within `radius` of i whose union with cluster i is smallest.  A block works on its 256 clusters from a copy in LDS that
 // reaches `radius` beyond both ends.
 __global__ void __launch_bounds__(kThreads)
 nearest_kernel(const Bounds6* box, uint32_t n, int radius, uint32_t* nearest) {
@@ -130,16 +129,24 @@ nearest_kernel(const Bounds6* box, uint32_t n, int radius, uint32_t* nearest) {
   const int i = (int)(blockIdx.x * kThreads + threadIdx.x);
   if (i >= (int)n) return;
   const Bounds6 mine = s_box[threadIdx.x + radius];
+  // Candidates by growing distance, the partner i ^ 1 first: among equal surfaces the earlier
+  // candidate wins, so that identical boxes (coincident objects) pair up two by two instead of
+  // all choosing the same lowest position, which would merge one pair per round.
   float best = __int_as_float(0x7F800000);
   int best_j = -1;
-  for (int dj = -radius; dj <= radius; ++dj) {
-    const int j = i + dj;
-    if (dj == 0 || j < 0 || j >= (int)n) continue;
-    float a = union_area(mine, s_box[(int)threadIdx.x + radius + dj]);
-    if (!(a < 3.0e38f)) a = 3.0e38f;  // (boxes that never cull have no finite surface: any partner will do)
-    if (a < best) {
-      best = a;
-      best_j = j;
+  const int toward = (i & 1) ? -1 : 1;
+  for (int k = 1; k <= radius; ++k) {
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+      const int dj = side == 0 ? toward * k : -toward * k;
+      const int j = i + dj;
+      if (j < 0 || j >= (int)n) continue;
+      float a = union_area(mine, s_box[(int)threadIdx.x + radius + dj]);
+      if (!(a < 3.0e38f)) a = 3.0e38f;  // (boxes that never cull have no finite surface: any partner will do)
+      if (a < best) {
+        best = a;
+        best_j = j;
+      }
     }
   }
   nearest[i] = (uint32_t)best_j;
@@ -404,7 +411,7 @@ std::string device_build_wide(hipStream_t stream, const std::vector<rt_bvh_node>
       if (left_over == 0 || left_over >= n_cur) return "device build: clustering made no progress";
       n_cur = left_over;
       cc ^= 1;
-      if (++steps > 100000u) return "device build: clustering did not end";
+      if (++steps > 4096u) return "device build: clustering did not end within 4096 rounds";
     }
     root = (uint32_t)n - 2u;  // the last merge made the last node
   }

@@ -169,7 +169,22 @@ def test_more_media_on_a_ray_than_the_postponed_list_holds(gpu_ctx, pipeline):
     assert np.array_equal(ids, rid) and np.array_equal(t, rt_) and np.array_equal(n, rn)
 
 
-@pytest.mark.parametrize("which", ["cover", "book2", "two_spheres"])
+def coincident_scene(n):
+    """n copies of one sphere and n of another (every surface n times: all hits tie in t) on a ground sphere."""
+    objs = "".join(f"Sphere(center: ({-0.6 if k % 2 else 0.6}, 0, -3), radius: 0.5, material: Shared(\"m{k % 3}\")),\n"
+                   for k in range(2 * n))
+    return """Scene(
+  image: (width: 64, height: 48, samples_per_pixel: 2, max_depth: 6),
+  camera: (look_from: (0, 0.5, 1), look_at: (0, 0, -3), vertical_fov: 40, aperture: 0),
+  background: (0.6, 0.7, 1.0),
+  materials: { "m0": Lambertian(albedo: Solid(0.8, 0.3, 0.3)), "m1": Metal(albedo: (0.8, 0.8, 0.8), fuzziness: 0.1),
+               "m2": Lambertian(albedo: Solid(0.2, 0.3, 0.8)) },
+  objects: [
+    Sphere(center: (0, -1000.5, -3), radius: 1000, material: Shared("m0")),
+""" + objs + "  ]\n)"
+
+
+@pytest.mark.parametrize("which", ["cover", "book2", "two_spheres", "coincident"])
 def test_device_built_hierarchy_gives_the_host_built_results(gpu_ctx, golden_dir, monkeypatch, which):
     """The hierarchy and the reference's resolution order made on the device (large scenes get
     them by default) against the host's: the order itself must be the host's (checked inside the
@@ -178,6 +193,8 @@ def test_device_built_hierarchy_gives_the_host_built_results(gpu_ctx, golden_dir
         scene = HostScene.generate_cover(60, scene_seed=5, width=160, height=90, spp=2, max_depth=12)
     elif which == "book2":
         scene, _ = load(golden_dir, "book2")
+    elif which == "coincident":  # identical boxes by the hundred, and every hit a tie decided by rank
+        scene = HostScene.load_ron_text(coincident_scene(300))
     else:
         scene, _ = load(golden_dir, "material_demo")
     w, h = scene.width, scene.height
@@ -191,6 +208,10 @@ def test_device_built_hierarchy_gives_the_host_built_results(gpu_ctx, golden_dir
         out[mode] = (ids, t, n, img)
     for a, b in zip(out["0"], out["1"]):
         assert np.array_equal(a, b)
+    if which == "coincident":  # and the ties resolve as the reference's own hierarchy would
+        o = po.Oracle(scene.view_ptr)
+        rid, rt_, rn = o.first_hit(w, h)
+        assert np.array_equal(out["1"][0], rid) and np.array_equal(out["1"][1], rt_)
 
 
 def test_stats_match_flat_oracle(gpu_ctx, golden_dir):
