@@ -204,3 +204,54 @@ def test_rust_mirror_follows_the_header():
         assert eval(size) == C.sizeof(cls), name
     fns = set(re.findall(r"pub fn (rt_\w+)\(", text))
     assert fns == set(abi.HOST_SYMBOLS + abi.DEVICE_SYMBOLS)
+
+
+def levelwise_reference_order(centres):
+    """The reference's resolution order by the scheme the device uses (bvh_device.hip): level l
+    sorts every range of 256 objects or more stably by box centre along axis l mod 3 (NaN last,
+    -0 = +0) and halves it; the upper half of every split comes first in the order."""
+    n = centres.shape[1]
+    perm = np.arange(n)
+    ranges = [(0, n)]
+    level = 0
+    while any(ln >= 256 for _, ln in ranges):
+        key = centres[level % 3][perm]
+        nxt = []
+        for lo, ln in ranges:
+            if ln < 256:
+                nxt.append((lo, ln))
+                continue
+            k = key[lo:lo + ln] + 0.0  # (-0 + 0 = +0)
+            order = np.lexsort((np.arange(ln), np.where(np.isnan(k), np.inf, k), np.isnan(k)))
+            perm[lo:lo + ln] = perm[lo:lo + ln][order]
+            half = ln // 2
+            nxt += [(lo, half), (lo + half, ln - half)]
+        ranges = nxt
+        level += 1
+
+    def emit(lo, ln):  # upper half first, all the way down
+        if ln < 256:
+            return list(perm[lo:lo + ln])
+        half = ln // 2
+        return emit(lo + half, ln - half) + emit(lo, half)
+    return np.array(emit(0, n))
+
+
+@pytest.mark.parametrize("half", [9, 20])
+def test_levelwise_sorts_give_the_reference_order(half):
+    """The device makes the tie-break order by one stable sort per level of the median-split
+    recursion instead of recursing (bvh.rs:33-77).  Same scheme in numpy against the ranks the host's
+    recursive sorts give: 328 spheres (one split) and 1604 (three levels; every y centre of the
+    small spheres equal, so the y level is all ties and only stability orders it)."""
+    from raytracer_amd.render import build_bvh
+    from raytracer_amd.scene import HostScene
+    scene = HostScene.generate_cover(half, scene_seed=7, width=64, height=36, spp=1, max_depth=5)
+    v = scene.view
+    n = v.n_objects
+    c = np.array([[v.prims[i].center[a] for i in range(n)] for a in range(3)])
+    r = np.array([v.prims[i].radius for i in range(n)])
+    centres = ((c + -r) + (c + r)) / 2.0  # sphere.rs:67-72, then the sort key of bvh.rs:47-53
+    _, items, _ = build_bvh(scene)
+    host_order = np.empty(n, dtype=np.int64)
+    host_order[items["rank"]] = items["object"]
+    assert np.array_equal(levelwise_reference_order(centres), host_order)
