@@ -4,8 +4,8 @@
 // What has to be preserved is results, not topology: the reference's own BVH
 // (BvhNode::new_along_axis, src/hittable/bvh.rs:33-77) only decides which of several objects
 // hit at exactly the same t is returned, and that order reaches the device as per-slot ranks
-// whichever hierarchy it walks (reference_order / reference_ranks_device).  Any conservative
-// hierarchy over the same leaf boxes returns the same hits.
+// whichever hierarchy it walks (reference_order on the host, device_reference_order below).
+// Any conservative hierarchy over the same leaf boxes returns the same hits.
 //
 //   1. Morton keys (21 bits per axis) of the leaf-box centres, radix-sorted (rocPRIM).
 //   2. Binary tree bottom-up by locally-ordered clustering: every cluster, at first the leaves
@@ -89,8 +89,8 @@ __device__ __forceinline__ Bounds6 box_of(uint32_t ref, const Bounds6* node_box,
 // has the smallest surface; two clusters that choose each other merge into a new node; the
 // array is compacted and the step repeats until one cluster is left.  Merging by surface area
 // instead of by key prefix gives a tree close to a top-down SAH build's (on the million-sphere
-// cover scene 49.5 box tests per ray against 47.1 for the host's sweep build, 55.0 for a radix tree
-// over the same keys with boxes fitted afterwards, and the host build's render time).
+// cover scene 49.5 box tests per ray against 47.1 for the host's sweep build and 55.0 for a radix tree
+// over the same keys with boxes fitted afterwards; render time as with the host's build).
 const int kMaxRadius = 32;
 
 __global__ void __launch_bounds__(kThreads)
@@ -115,8 +115,8 @@ __device__ __forceinline__ float union_area(const Bounds6& a, const Bounds6& b) 
   return x * y + y * z + z * x;
 }
 
-// nearest[i]: the position within `radius` of i whose union with cluster i is smallest.  A block works on its 256 clusters from a copy in LDS that
-// reaches `radius` beyond both ends.
+// nearest[i]: the position within `radius` of i whose union with cluster i is smallest.  A block
+// works on its 256 clusters from a copy in LDS that reaches `radius` beyond both ends.
 __global__ void __launch_bounds__(kThreads)
 nearest_kernel(const Bounds6* box, uint32_t n, int radius, uint32_t* nearest) {
   __shared__ Bounds6 s_box[kThreads + 2 * kMaxRadius];
