@@ -211,8 +211,10 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "r02_trace_kernel_hbm_traffic.json")
         if fused and os.path.exists(tpath) and (args.width, args.height) == (WIDTH, HEIGHT) and args.spp >= 64:
             with open(tpath) as f:
-                result["roofline"]["traffic"] = json.load(f)["hbm_bytes_per_launch"]
-            result["roofline"]["traffic_unit"] = "bytes per launch (HBM, PMC passes at 64 spp per pass)"
+                tj = json.load(f)
+            result["roofline"]["traffic"] = tj["hbm_bytes_per_launch"]
+            result["roofline"]["traffic_unit"] = ("bytes per launch (HBM, separate PMC passes over one pass of %d spp)"
+                                                  % tj.get("samples_per_pass", 64))
         if not args.no_cpu:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import pyoracle as po

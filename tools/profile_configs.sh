@@ -9,8 +9,9 @@ run() {  # name scene spp w h
   python3 tools/prof_summary.py gpurun_out/prof_${R}_$1 > gpurun_out/$R/${R}_$1_rocprof.txt
   rm -rf gpurun_out/prof_${R}_$1
 }
-run book_cover book_cover 64 1920 1080
-run cornell cornell 64 1024 1024
-run book2 book2 64 1920 1080
-run cover1m cover1m 16 3840 2160
+# one pass of the default pass size each (2^30 paths)
+run book_cover book_cover 512 1920 1080
+run cornell cornell 512 1024 1024
+run book2 book2 256 1920 1080
+run cover1m cover1m 64 3840 2160
 ls -la gpurun_out/$R
