@@ -1374,6 +1374,11 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats, d
     accum = ctx->accum.p;
     per_pass = (uint32_t)std::min<uint64_t>(ctx->max_paths / n_pix, n_samples);
     if (per_pass == 0) per_pass = 1;
+    // passes of equal size (1024 samples with room for 486 at a time: 342 + 341 + 341, not 486 + 486 + 52)
+    if (n_samples) {
+      const uint32_t n_passes = (n_samples + per_pass - 1) / per_pass;
+      per_pass = (n_samples + n_passes - 1) / n_passes;
+    }
   }
   *accum_out = accum;
   RT_HIP(ctx, hipMemsetAsync(accum, 0, n_pix * 3 * sizeof(double), ctx->stream));
@@ -1388,7 +1393,12 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats, d
   }
 
   if (!in_scratch) {
-    rc = ensure_paths(ctx, n_pix * per_pass, p->max_depth, queues);
+    // (device memory that turns out not to be there after all: smaller passes)
+    while ((rc = ensure_paths(ctx, n_pix * per_pass, p->max_depth, queues)) == RT_ERR_NOMEM && per_pass > 1) {
+      (void)hipGetLastError();
+      free_paths(ctx);
+      per_pass = (per_pass + 1) / 2;
+    }
     if (rc != RT_OK) return rc;
   }
   const PathBuffers& pb = in_scratch ? scratch_pb : ctx->pb;
