@@ -940,6 +940,16 @@ std::string flatten_scene(const rt_scene& s, FlatScene& out, int& code, const Wi
         out.stack_entries = stack_need(out.nodes);
         lap("stack bound");
         built = true;
+        // Clustering has no depth bound of its own (nested boxes merge one leaf at a time): a
+        // hierarchy whose walk could need more than 64 stack entries is left to the host's
+        // build, which bounds its depth by construction.
+        if (out.stack_entries > 64) {
+          if (timing) fprintf(stderr, "mi355rt: device-built hierarchy needs %u stack entries; building on the host\n",
+                              out.stack_entries);
+          built = false;
+          out.nodes.clear();
+          leaf_order.clear();
+        }
       } else {  // the host's build serves every scene
         if (timing) fprintf(stderr, "mi355rt: %s; building on the host\n", err.c_str());
         out.nodes.clear();

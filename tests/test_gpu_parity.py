@@ -184,7 +184,21 @@ def coincident_scene(n):
 """ + objs + "  ]\n)"
 
 
-@pytest.mark.parametrize("which", ["cover", "book2", "two_spheres", "coincident"])
+def nested_scene(n):
+    """n concentric glass shells: clustering merges them one at a time into a hierarchy n levels deep."""
+    objs = "".join(f"Sphere(center: (0, 0, -3), radius: {0.2 + 0.004 * k}, material: Shared(\"glass\")),\n"
+                   for k in range(n))
+    return """Scene(
+  image: (width: 64, height: 48, samples_per_pixel: 2, max_depth: 6),
+  camera: (look_from: (0, 0.5, 1), look_at: (0, 0, -3), vertical_fov: 40, aperture: 0),
+  background: (0.6, 0.7, 1.0),
+  materials: { "glass": Dielectric(index_of_refraction: 1.5), "m0": Lambertian(albedo: Solid(0.8, 0.3, 0.3)) },
+  objects: [
+    Sphere(center: (0, -1000.5, -3), radius: 1000, material: Shared("m0")),
+""" + objs + "  ]\n)"
+
+
+@pytest.mark.parametrize("which", ["cover", "book2", "two_spheres", "coincident", "nested"])
 def test_device_built_hierarchy_gives_the_host_built_results(gpu_ctx, golden_dir, monkeypatch, which):
     """The hierarchy and the reference's resolution order made on the device (large scenes get
     them by default) against the host's: the order itself must be the host's (checked inside the
@@ -195,6 +209,8 @@ def test_device_built_hierarchy_gives_the_host_built_results(gpu_ctx, golden_dir
         scene, _ = load(golden_dir, "book2")
     elif which == "coincident":  # identical boxes by the hundred, and every hit a tie decided by rank
         scene = HostScene.load_ron_text(coincident_scene(300))
+    elif which == "nested":  # deeper than the device build may go: it hands over to the host's
+        scene = HostScene.load_ron_text(nested_scene(200))
     else:
         scene, _ = load(golden_dir, "material_demo")
     w, h = scene.width, scene.height
