@@ -336,6 +336,16 @@ int rt_render_device(rt_ctx* ctx, const rt_render_params* p, float* d_rgb_sum, u
 #define RT_NOALLOC_SCRATCH_BYTES (64u << 20)
 int rt_render_device_noalloc(rt_ctx* ctx, const rt_render_params* p, float* d_rgb_sum);
 
+/* Replaces the progress bar of src/main.rs:58-61,83,99 (one tick per finished pixel there).
+ * While a callback is set, every render call on `ctx` calls fn(user, done, total) after each
+ * finished pass over the window: done and total count pixel-samples of that call, done grows
+ * to total.  Single context: called from the thread that renders.  Device group: from the
+ * threads that drive the members, never two at a time.  The render waits for a pass to
+ * finish before it queues the next one, which costs a little; fn == NULL removes the
+ * callback.  The callback must not call into the library with the same context. */
+typedef void (*rt_progress_fn)(void* user, uint64_t done, uint64_t total);
+int rt_set_progress(rt_ctx* ctx, rt_progress_fn fn, void* user);
+
 /* Deterministic parity pass: pinhole rays through pixel centres
  * (u=(x+0.5)/(w-1), v=((h-y)+0.5)/(h-1), lens offset 0, time = shutter start),
  * world.hit(ray, 0.001..inf) (src/main.rs:123) with constant media left out.

@@ -138,6 +138,9 @@ class BvhItem(C.Structure):
                 ("reserved", C.c_uint32)]
 
 
+# void fn(void* user, uint64_t done, uint64_t total)
+ProgressFn = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_uint64)
+
 HOST_SYMBOLS = [
     "rt_host_add_asset_dir", "rt_host_load_ron", "rt_host_load_ron_text", "rt_host_save_frozen",
     "rt_host_load_frozen", "rt_host_generate_cover", "rt_host_set_image", "rt_host_scene_view",
@@ -146,7 +149,7 @@ HOST_SYMBOLS = [
 ]
 DEVICE_SYMBOLS = [
     "rt_create", "rt_upload_scene", "rt_render", "rt_render_f64", "rt_render_device",
-    "rt_render_device_noalloc", "rt_first_hit", "rt_bvh_build", "rt_bvh_info", "rt_bvh_copy", "rt_bvh_free", "rt_last_error",
+    "rt_render_device_noalloc", "rt_set_progress", "rt_first_hit", "rt_bvh_build", "rt_bvh_info", "rt_bvh_copy", "rt_bvh_free", "rt_last_error",
     "rt_destroy",
 ]
 
@@ -209,6 +212,7 @@ def device_lib():
     L.rt_render_f64.argtypes = [vp, C.POINTER(RenderParams), vp, vp]
     L.rt_render_device.argtypes = [vp, C.POINTER(RenderParams), vp, vp]
     L.rt_render_device_noalloc.argtypes = [vp, C.POINTER(RenderParams), vp]
+    L.rt_set_progress.argtypes = [vp, ProgressFn, vp]
     L.rt_first_hit.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(Window), vp, vp, vp]
     L.rt_bvh_build.argtypes = [C.POINTER(Scene), C.POINTER(vp)]
     L.rt_bvh_info.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),

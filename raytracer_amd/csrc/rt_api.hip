@@ -38,6 +38,7 @@
 #include <string>
 #include <limits>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <dlfcn.h>
 #include <type_traits>
@@ -1019,6 +1020,13 @@ struct rt_ctx {
   DeviceArray<float> share;
   void* rccl = nullptr;                // dlopen handle of librccl
   std::vector<void*> comms;            // ncclComm_t per member, root first
+  // Progress of a render call (rt_set_progress): the callback lives on the context the caller
+  // holds; the members of a group report to it through `progress_to`, one at a time.
+  rt_progress_fn progress_fn = nullptr;
+  void* progress_user = nullptr;
+  rt_ctx* progress_to = nullptr;  // set on a member while its group renders
+  std::mutex progress_mutex;
+  uint64_t progress_done = 0, progress_total = 0;
 };
 
 namespace {
@@ -1403,6 +1411,11 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats, d
   }
   const PathBuffers& pb = in_scratch ? scratch_pb : ctx->pb;
   const uint32_t max_grid = ctx->n_cus * ctx->blocks_per_cu;
+  rt_ctx* const report = ctx->progress_to ? ctx->progress_to : ctx;
+  if (!ctx->progress_to) {  // (a group sets its totals itself)
+    ctx->progress_done = 0;
+    ctx->progress_total = n_pix * n_samples;
+  }
 
   for (uint32_t done = 0; done < n_samples; done += per_pass) {
     ps.samples = std::min(per_pass, n_samples - done);
@@ -1472,6 +1485,13 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats, d
       }
     }
     resolve_kernel<<<blocks_for(n_pix), kBlock, 0, ctx->stream>>>(pb, ps, accum);
+    if (report->progress_fn) {
+      // a pass counts once it has finished: wait for it (only callers that asked pay for this)
+      RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      std::lock_guard<std::mutex> lock(report->progress_mutex);
+      report->progress_done += n_pix * ps.samples;
+      report->progress_fn(report->progress_user, report->progress_done, report->progress_total);
+    }
   }
   RT_HIP(ctx, hipGetLastError());
   RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1832,6 +1852,17 @@ static int render_group(rt_ctx* root, const rt_render_params* p, float* d_out, u
   const uint64_t total = p->sample_end - p->sample_begin;
   std::vector<int> codes(N, RT_OK);
   std::vector<std::vector<uint64_t>> member_stats(N, std::vector<uint64_t>(stats ? RT_STAT_COUNT : 0));
+  root->progress_done = 0;
+  root->progress_total = (uint64_t)ps.n_pixels * total;
+  struct ReportToRoot {  // every member, the root included, reports to the root while the group renders
+    std::vector<rt_ctx*>& m;
+    ReportToRoot(std::vector<rt_ctx*>& members, rt_ctx* to) : m(members) {
+      for (rt_ctx* c : m) c->progress_to = to;
+    }
+    ~ReportToRoot() {
+      for (rt_ctx* c : m) c->progress_to = nullptr;
+    }
+  } report_to_root(members, root);
   auto work = [&](uint32_t k) {
     rt_ctx* m = members[k];
     auto run = [&]() -> int {
@@ -1916,6 +1947,14 @@ int rt_render_device(rt_ctx* ctx, const rt_render_params* p, float* d_rgb_sum, u
   to_float_kernel<<<blocks_for(n), kBlock, 0, ctx->stream>>>(accum, d_rgb_sum, n);
   RT_HIP(ctx, hipGetLastError());
   RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return RT_OK;
+}
+
+int rt_set_progress(rt_ctx* ctx, rt_progress_fn fn, void* user) {
+  if (!ctx) return RT_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(ctx->progress_mutex);
+  ctx->progress_fn = fn;
+  ctx->progress_user = fn ? user : nullptr;
   return RT_OK;
 }
 

@@ -9,15 +9,48 @@
 #include <string>
 #include <vector>
 
+#include <unistd.h>
+
 #include "../../include/mi355rt.h"
+
+// The reference's progress line (src/main.rs:58-61: "{bar} {human_pos}/{human_len} ({percent}%)
+// {elapsed_precise}" over the pixel count), redrawn after every finished pass of the render.
+struct Bar {
+  uint64_t pixels;
+  std::chrono::steady_clock::time_point start;
+};
+static std::string with_commas(uint64_t v) {
+  std::string digits = std::to_string(v), out;
+  for (size_t i = 0; i < digits.size(); ++i) {
+    if (i && (digits.size() - i) % 3 == 0) out += ',';
+    out += digits[i];
+  }
+  return out;
+}
+static void draw_bar(void* user, uint64_t done, uint64_t total) {
+  const Bar* bar = (const Bar*)user;
+  const double part = total ? (double)done / (double)total : 1.0;
+  const int cells = 20, full = (int)(part * cells);
+  std::string line;
+  for (int i = 0; i < cells; ++i) line += i < full ? "\xe2\x96\x88" : "\xe2\x96\x91";
+  const uint64_t secs = (uint64_t)std::chrono::duration_cast<std::chrono::seconds>(
+                            std::chrono::steady_clock::now() - bar->start).count();
+  std::fprintf(stderr, "\r%s %s/%s (%d%%) %02llu:%02llu:%02llu", line.c_str(),
+               with_commas((uint64_t)(part * (double)bar->pixels)).c_str(), with_commas(bar->pixels).c_str(),
+               (int)(part * 100.0), (unsigned long long)(secs / 3600), (unsigned long long)(secs / 60 % 60),
+               (unsigned long long)(secs % 60));
+  std::fflush(stderr);
+}
 
 static void usage() {
   std::fprintf(stderr,
                "usage: raytracer <scene.ron|scene.rtscene> [--width N] [--height N] [--spp N]\n"
                "       [--max-depth N] [--seed N] [--scene-seed N] [--device N] [--out image.png]\n"
                "       [--assets DIR] [--freeze out.rtscene] [--gpus N | --devices a,b,...]\n"
-               "       [--dump-pfm linear.pfm] [--first-hit hits.rtfh]\n"
+               "       [--dump-pfm linear.pfm] [--first-hit hits.rtfh] [--progress | --no-progress]\n"
                "  --gpus N         render on devices 0..N-1 (sample ranges, one reduce onto device 0)\n"
+               "  --progress       draw the progress line on stderr after every pass (default: when stderr\n"
+               "                   is a terminal)\n"
                "  --dump-pfm F     also write the linear per-pixel mean radiance (before the clamp and the\n"
                "                   8-bit resolve) as a little-endian RGB PFM\n"
                "  --first-hit F    also write the pinhole pixel-centre first-hit pass: 'RTFH', width, height\n"
@@ -35,6 +68,7 @@ int main(int argc, char** argv) {
   opt.scene_seed = 1;
   uint64_t seed = 1;
   int device = 0;
+  bool progress = isatty(fileno(stderr)) != 0;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     auto next = [&](const char* what) -> const char* {
@@ -56,6 +90,8 @@ int main(int argc, char** argv) {
     else if (a == "--freeze") freeze = next("--freeze");
     else if (a == "--dump-pfm") pfm = next("--dump-pfm");
     else if (a == "--first-hit") first_hit = next("--first-hit");
+    else if (a == "--progress") progress = true;
+    else if (a == "--no-progress") progress = false;
     else if (a == "--gpus") {
       int n = std::atoi(next("--gpus"));
       devices.clear();
@@ -127,6 +163,11 @@ int main(int argc, char** argv) {
   p.sample_end = spp;
   p.max_depth = depth;
   p.seed = seed;
+  Bar bar{(uint64_t)w * h, start};
+  if (progress) {
+    rt_set_progress(ctx, draw_bar, &bar);
+    draw_bar(&bar, 0, 1);
+  }
   if (devices.size() > 1) {  // a device group adds float shares
     std::vector<float> fsum(sum.size());
     if (rt_render(ctx, &p, fsum.data(), nullptr) != RT_OK) {
@@ -137,6 +178,10 @@ int main(int argc, char** argv) {
   } else if (rt_render_f64(ctx, &p, sum.data(), nullptr) != RT_OK) {
     std::fprintf(stderr, "Error: %s\n", rt_last_error(ctx));
     return 1;
+  }
+  if (progress) {
+    rt_set_progress(ctx, nullptr, nullptr);
+    std::fputc('\n', stderr);
   }
   if (!pfm.empty()) {  // PFM rows run bottom to top; a negative scale means little-endian
     FILE* f = std::fopen(pfm.c_str(), "wb");

@@ -89,6 +89,12 @@ class Context:
         """render_into through the entry point that allocates nothing (fixed scratch array)."""
         self._check(abi.device_lib().rt_render_device_noalloc(self._h, C.byref(p), C.c_void_p(device_ptr)))
 
+    def set_progress(self, fn):
+        """fn(done, total), in pixel-samples of the running call, after every finished pass; None removes it."""
+        # (the ctypes thunk has to outlive the registration)
+        self._progress = abi.ProgressFn((lambda user, done, total: fn(done, total))) if fn else abi.ProgressFn()
+        self._check(abi.device_lib().rt_set_progress(self._h, self._progress, None))
+
     def first_hit(self, width, height, window=None):
         L = abi.device_lib()
         w = abi.Window(*window) if window is not None else abi.Window(0, 0, 0, 0)

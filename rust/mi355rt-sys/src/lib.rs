@@ -3,7 +3,7 @@
 //! sides are held to (`tests/test_abi.py`).
 #![allow(non_camel_case_types)]
 use core::mem::size_of;
-use std::os::raw::{c_char, c_int};
+use std::os::raw::{c_char, c_int, c_void};
 
 pub const RT_OK: c_int = 0;
 pub const RT_ERR_INVALID: c_int = -1;
@@ -256,6 +256,9 @@ pub enum rt_ctx {}
 pub enum rt_bvh {}
 pub enum rt_host_scene {}
 
+/// `void fn(void* user, uint64_t done, uint64_t total)`; `None` removes the callback.
+pub type rt_progress_fn = Option<unsafe extern "C" fn(user: *mut c_void, done: u64, total: u64)>;
+
 extern "C" {
     // ---- host front-end (libmi355rt_host.so) ----
     pub fn rt_host_add_asset_dir(dir: *const c_char) -> c_int;
@@ -285,6 +288,7 @@ extern "C" {
     pub fn rt_render_f64(ctx: *mut rt_ctx, p: *const rt_render_params, rgb_sum: *mut f64, stats: *mut u64) -> c_int;
     pub fn rt_render_device(ctx: *mut rt_ctx, p: *const rt_render_params, d_rgb_sum: *mut f32, stats: *mut u64) -> c_int;
     pub fn rt_render_device_noalloc(ctx: *mut rt_ctx, p: *const rt_render_params, d_rgb_sum: *mut f32) -> c_int;
+    pub fn rt_set_progress(ctx: *mut rt_ctx, f: rt_progress_fn, user: *mut c_void) -> c_int;
     pub fn rt_first_hit(ctx: *mut rt_ctx, width: u32, height: u32, window: *const rt_window, id: *mut u32,
                         t: *mut f64, normal: *mut f64) -> c_int;
     pub fn rt_bvh_build(scene: *const rt_scene, out: *mut *mut rt_bvh) -> c_int;

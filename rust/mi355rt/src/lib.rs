@@ -13,6 +13,13 @@ use std::ffi::CStr;
 pub struct Gpu {
     ctx: *mut sys::rt_ctx,
     _devices: Vec<i32>,
+    // boxed twice: the library keeps a thin pointer to the inner (fat) box
+    progress: Option<Box<Box<dyn FnMut(u64, u64) + Send>>>,
+}
+
+unsafe extern "C" fn progress_thunk(user: *mut std::os::raw::c_void, done: u64, total: u64) {
+    let f = &mut *(user as *mut Box<dyn FnMut(u64, u64) + Send>);
+    f(done, total);
 }
 
 impl Gpu {
@@ -28,7 +35,7 @@ impl Gpu {
         let mut ctx = std::ptr::null_mut();
         let rc = unsafe { sys::rt_create(&cfg, &mut ctx) };
         anyhow::ensure!(rc == sys::RT_OK, "no usable HIP device (rt_create: {rc})");
-        Ok(Self { ctx, _devices: devices })
+        Ok(Self { ctx, _devices: devices, progress: None })
     }
 
     fn error(&self) -> anyhow::Error {
@@ -41,6 +48,21 @@ impl Gpu {
             return Err(self.error()).context("uploading scene");
         }
         Ok(())
+    }
+
+    /// `f(done, total)` in pixel-samples after every finished pass of a render: what drives the
+    /// `indicatif` bar of src/main.rs:58-61 (`bar.set_position(done / samples_per_pixel)`).
+    /// A device group calls it from its member threads, one at a time, hence `Send`.
+    pub fn set_progress(&mut self, f: Option<Box<dyn FnMut(u64, u64) + Send>>) {
+        self.progress = f.map(Box::new);
+        match self.progress.as_mut() {
+            Some(b) => unsafe {
+                sys::rt_set_progress(self.ctx, Some(progress_thunk), &mut **b as *mut Box<_> as *mut _);
+            },
+            None => unsafe {
+                sys::rt_set_progress(self.ctx, None, std::ptr::null_mut());
+            },
+        }
     }
 
     /// Sums over samples `[0, samples_per_pixel)` of `ray_color` per pixel, row 0 on top, RGB.

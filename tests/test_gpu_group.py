@@ -108,3 +108,48 @@ def test_cli_linear_dump_and_first_hit(gpu_ctx, golden_dir, tmp_path):
     t = np.frombuffer(raw[12 + 4 * n:12 + 12 * n], dtype="<f8").reshape(h, w)
     rid, rt_, _ = gpu_ctx.first_hit(w, h)
     assert np.array_equal(ids, rid) and np.array_equal(t, rt_)
+
+
+def test_progress_is_reported_after_every_pass(gpu_ctx, golden_dir):
+    """rt_set_progress (the reference's progress bar, main.rs:58-61,99): done grows pass by pass to total,
+    the image is the one rendered without a callback, and removing the callback stops the reports."""
+    from raytracer_amd.render import Context
+    scene = HostScene.load_frozen(os.path.join(golden_dir, "book_cover.rtscene"))
+    w, h = scene.width, scene.height
+    gpu_ctx.upload(scene)
+    plain = gpu_ctx.render(gpu_ctx.params(w, h, 0, 7, 50, seed=3), dtype=np.float64)
+    small = Context(device=0, max_paths_in_flight=2 * w * h + 5)  # 2 samples at a time: 4 passes of 2, 2, 2, 1
+    try:
+        small.upload(scene)
+        seen = []
+        small.set_progress(lambda done, total: seen.append((done, total)))
+        image = small.render(small.params(w, h, 0, 7, 50, seed=3), dtype=np.float64)
+        assert np.array_equal(image, plain)
+        assert seen == [(k * w * h, 7 * w * h) for k in (2, 4, 6, 7)]
+        del seen[:]
+        small.render(small.params(w, h, 2, 5, 50, seed=3, window=(8, 4, 16, 8)), dtype=np.float64)
+        assert seen == [(3 * 16 * 8, 3 * 16 * 8)]  # one pass; each call counts from zero, in its own window
+        del seen[:]
+        small.set_progress(None)
+        small.render(small.params(w, h, 0, 3, 50, seed=3), dtype=np.float64)
+        assert seen == []
+    finally:
+        small.close()
+
+
+def test_progress_of_a_device_group_counts_every_member(gpu_ctx, golden_dir):
+    from raytracer_amd.render import Context
+    scene = HostScene.load_frozen(os.path.join(golden_dir, "cornell.rtscene"))
+    w, h = scene.width, scene.height
+    group = Context(devices=[0, 0], max_paths_in_flight=2 * w * h)
+    try:
+        group.upload(scene)
+        seen = []
+        group.set_progress(lambda done, total: seen.append((done, total)))
+        group.render(group.params(w, h, 0, 6, 20, seed=9))
+        # two members of three samples each, two passes each (2 + 1 samples): four reports, in any order
+        assert len(seen) == 4 and all(t == 6 * w * h for _, t in seen)
+        done = [d for d, _ in seen]
+        assert done == sorted(done) and done[-1] == 6 * w * h
+    finally:
+        group.close()

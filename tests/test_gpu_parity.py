@@ -381,6 +381,15 @@ def test_command_line_renderer_end_to_end(gpu_ctx, tmp_path):
                        text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     assert "Done in" in r.stdout + r.stderr
+    assert r.stderr == ""  # (no progress line unless stderr is a terminal or --progress asks)
+    bar = subprocess.run([exe, str(ron), "--spp", "5", "--seed", "7", "--out", str(tmp_path / "again.png"),
+                          "--progress"], capture_output=True, timeout=120)
+    shown = HostScene.load_ron_text(text)
+    n_pixels = format(shown.width * shown.height, ",")
+    last = bar.stderr.decode("utf-8", "replace").rstrip("\n").split("\r")[-1]
+    assert bar.returncode == 0 and last.split(" ", 1)[1].startswith(
+        f"{n_pixels}/{n_pixels} (100%) 00:00:0"), last  # main.rs:59-61
+    assert (tmp_path / "again.png").read_bytes() == out.read_bytes()
     got = np.asarray(Image.open(io.BytesIO(out.read_bytes())).convert("RGB"))
     scene = HostScene.load_ron_text(text)
     gpu_ctx.upload(scene)
