@@ -1008,7 +1008,7 @@ struct rt_ctx {
   uint32_t trace_block = 256;   // threads per trace_kernel workgroup: 256, 512 or 1024
   uint32_t trace_blocks_per_cu = 16;
   uint32_t blocks_per_cu = 16;  // 256-thread workgroups per CU in a grid (extend, shade, first hit)
-  uint32_t tail_paths = 1u << 18;  // fused pipeline: at most this many live paths finish in one launch
+  uint32_t tail_paths = 1u << 20;  // fused pipeline: at most this many live paths finish in one launch
   DeviceArray<uint32_t> stack_overflow;
   std::vector<hipEvent_t> events;  // RT_FLAG_TIMING: three per bounce (before extend, between, after shade)
   DeviceArray<unsigned char> staging;     // device side of host-buffer results (rt_render, rt_first_hit)
