@@ -249,7 +249,14 @@ typedef struct rt_config {
    * pixel (the pixel-sample space of src/main.rs:87-97 shards by sample range) and add the
    * float shares onto the root with one reduce(sum) over RCCL communicators the context owns
    * (ncclCommInitAll in this process).  rt_render_device's buffer lives on the root's device.
-   * rt_first_hit runs on the root; rt_render_f64 and rt_render_device_noalloc are not for groups. */
+   * rt_first_hit runs on the root; rt_render_f64 and rt_render_device_noalloc are not for groups.
+   * A group of distinct devices needs librccl (looked up at run time): without it rt_create fails,
+   * unless MI355RT_STAGED_REDUCE=1 asks for the shares to be added through host memory instead.
+   * A group that names one device more than once cannot have communicators and always adds
+   * through host memory (a rehearsal of the group logic on a one-GPU machine).  n_devices == 1
+   * with MI355RT_FORCE_RCCL=1 makes a group of one member with a one-rank communicator, so that
+   * the whole RCCL path (lookup, ncclCommInitAll, ncclGroupStart/End, ncclReduce on the member's
+   * stream) can run on a machine with a single GPU.  rt_group_info says which path a context uses. */
   const int32_t* devices;
 } rt_config;
 
@@ -379,6 +386,22 @@ int rt_bvh_build(const rt_scene* scene, rt_bvh** out);
 int rt_bvh_info(const rt_bvh* bvh, uint32_t* n_nodes, uint32_t* n_items, uint32_t* max_depth);
 int rt_bvh_copy(const rt_bvh* bvh, rt_bvh_node* nodes, rt_bvh_item* items);
 void rt_bvh_free(rt_bvh* bvh);
+
+/* How a context adds the shares of its members (the cross-device form of the per-pixel
+ * `.sum()` over samples, src/main.rs:97), and what the last render call on it spent where. */
+typedef enum rt_reduce_path {
+  RT_REDUCE_NONE = 0,        /* one device: nothing to add */
+  RT_REDUCE_RCCL = 1,        /* one ncclReduce(sum, float32) to the root over the group's communicators */
+  RT_REDUCE_HOST_STAGED = 2  /* shares copied to the host, added there, the sums copied back */
+} rt_reduce_path;
+typedef struct rt_group_report {
+  uint32_t n_members;      /* 1 for a plain context */
+  uint32_t reduce_path;    /* rt_reduce_path */
+  double render_ms_min;    /* last render call: the fastest and the slowest member's share, host clock */
+  double render_ms_max;
+  double reduce_ms;        /* last render call: from the last member's end to the sums on the root */
+} rt_group_report;
+int rt_group_info(const rt_ctx* ctx, rt_group_report* out);
 
 const char* rt_last_error(const rt_ctx* ctx);
 void rt_destroy(rt_ctx* ctx);

@@ -129,6 +129,14 @@ class RenderParams(C.Structure):
     ]
 
 
+class GroupReport(C.Structure):
+    _fields_ = [("n_members", C.c_uint32), ("reduce_path", C.c_uint32), ("render_ms_min", C.c_double),
+                ("render_ms_max", C.c_double), ("reduce_ms", C.c_double)]
+
+
+REDUCE_PATHS = ["none", "rccl", "host-staged"]  # rt_reduce_path
+
+
 class BvhNode(C.Structure):
     _fields_ = [("lo", C.c_float * 3), ("hi", C.c_float * 3), ("a", C.c_uint32), ("b", C.c_uint32)]
 
@@ -149,7 +157,7 @@ HOST_SYMBOLS = [
 ]
 DEVICE_SYMBOLS = [
     "rt_create", "rt_upload_scene", "rt_render", "rt_render_f64", "rt_render_device",
-    "rt_render_device_noalloc", "rt_set_progress", "rt_first_hit", "rt_bvh_build", "rt_bvh_info", "rt_bvh_copy", "rt_bvh_free", "rt_last_error",
+    "rt_render_device_noalloc", "rt_set_progress", "rt_group_info", "rt_first_hit", "rt_bvh_build", "rt_bvh_info", "rt_bvh_copy", "rt_bvh_free", "rt_last_error",
     "rt_destroy",
 ]
 
@@ -213,6 +221,7 @@ def device_lib():
     L.rt_render_device.argtypes = [vp, C.POINTER(RenderParams), vp, vp]
     L.rt_render_device_noalloc.argtypes = [vp, C.POINTER(RenderParams), vp]
     L.rt_set_progress.argtypes = [vp, ProgressFn, vp]
+    L.rt_group_info.argtypes = [vp, C.POINTER(GroupReport)]
     L.rt_first_hit.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(Window), vp, vp, vp]
     L.rt_bvh_build.argtypes = [C.POINTER(Scene), C.POINTER(vp)]
     L.rt_bvh_info.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),

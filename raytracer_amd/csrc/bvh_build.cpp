@@ -736,11 +736,14 @@ std::string flatten_scene(const rt_scene& s, FlatScene& out, int& code, const Wi
           centres[(size_t)a * s.n_objects + i] = (ref_boxes[i].lo[a] + ref_boxes[i].hi[a]) / 2.0;
     });
     std::string err = (*ref_order)(centres, s.n_objects, order);
-    if (!err.empty()) {
-      code = RT_ERR_DEVICE;
-      return err;
-    }
-    if (getenv("MI355RT_CHECK_ORDER")) {  // development: the host's sorts must give the same order
+    if (!err.empty()) {  // the host's recursive sorts give the same order; the caller clears the device's error state
+      if (getenv("MI355RT_DEBUG")) fprintf(stderr, "mi355rt: device reference order failed (%s): host sorts instead\n", err.c_str());
+      std::vector<uint32_t> ids(s.n_objects);
+      std::iota(ids.begin(), ids.end(), 0u);
+      order.clear();
+      order.reserve(s.n_objects);
+      reference_order(ref_boxes, ids, 0, order);
+    } else if (getenv("MI355RT_CHECK_ORDER")) {  // development: the host's sorts must give the same order
       std::vector<uint32_t> ids(s.n_objects), host_order;
       std::iota(ids.begin(), ids.end(), 0u);
       reference_order(ref_boxes, ids, 0, host_order);

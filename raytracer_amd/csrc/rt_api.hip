@@ -1020,6 +1020,9 @@ struct rt_ctx {
   DeviceArray<float> share;
   void* rccl = nullptr;                // dlopen handle of librccl
   std::vector<void*> comms;            // ncclComm_t per member, root first
+  bool group = false;                  // render calls go through render_group (peers, or a forced group of one)
+  uint32_t reduce_path = RT_REDUCE_NONE;
+  double last_render_ms_min = 0.0, last_render_ms_max = 0.0, last_reduce_ms = 0.0;  // rt_group_info
   // Progress of a render call (rt_set_progress): the callback lives on the context the caller
   // holds; the members of a group report to it through `progress_to`, one at a time.
   rt_progress_fn progress_fn = nullptr;
@@ -1596,7 +1599,10 @@ int rt_create(const rt_config* cfg, rt_ctx** out) {
   rt_ctx* root = nullptr;
   int rc = create_single(n > 1 ? cfg->devices[0] : n == 1 && cfg->devices ? cfg->devices[0] : cfg ? cfg->device : 0,
                          max_paths, &root);
-  if (rc != RT_OK || n <= 1) {
+  // a group of one member with a one-rank communicator: the RCCL path on a machine with one GPU
+  const char* force = getenv("MI355RT_FORCE_RCCL");
+  const bool group_of_one = n == 1 && cfg->devices && force && atoi(force);
+  if (rc != RT_OK || (n <= 1 && !group_of_one)) {
     *out = root;
     return rc;
   }
@@ -1611,26 +1617,51 @@ int rt_create(const rt_config* cfg, rt_ctx** out) {
     root->peers.push_back(peer);
     for (uint32_t j = 0; j < k; ++j) distinct = distinct && cfg->devices[j] != cfg->devices[k];
   }
+  root->group = true;
   // One communicator per member, made in this one process (ncclCommInitAll).  A group that names
   // a device twice (two shares on one GPU: a rehearsal on a single-GPU machine) cannot have
-  // one, nor can a machine without librccl: such groups add their shares through host memory.
+  // one and adds its shares through host memory.  A group of distinct devices without a usable
+  // librccl is an error, not a quiet detour through the host: MI355RT_STAGED_REDUCE=1 asks for
+  // that detour in so many words.
   const char* staged = getenv("MI355RT_STAGED_REDUCE");
+  root->reduce_path = RT_REDUCE_HOST_STAGED;
   if (distinct && !(staged && atoi(staged))) {
+    auto give_up = [&](const std::string& why) {
+      fprintf(stderr, "mi355rt: %s (set MI355RT_STAGED_REDUCE=1 to add the shares through host memory)\n",
+              why.c_str());
+      rt_destroy(root);
+      return RT_ERR_DEVICE;
+    };
     root->rccl = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!root->rccl) root->rccl = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-    Rccl r;
-    if (root->rccl && load_rccl(root->rccl, r)) {
-      root->comms.assign(n, nullptr);
-      int nrc = r.CommInitAll(root->comms.data(), (int)n, cfg->devices);
-      if (nrc != 0) {
-        root->error = std::string("ncclCommInitAll: ") + r.GetErrorString(nrc);
-        root->comms.clear();
-        rt_destroy(root);
-        return RT_ERR_DEVICE;
-      }
+    if (!root->rccl) {
+      const char* why = dlerror();
+      return give_up(std::string("a device group needs librccl: ") + (why ? why : "not found"));
     }
+    Rccl r;
+    if (!load_rccl(root->rccl, r)) return give_up("librccl lacks one of the six entry points the group reduce uses");
+    root->comms.assign(n, nullptr);
+    int nrc = r.CommInitAll(root->comms.data(), (int)n, cfg->devices);
+    if (nrc != 0) {
+      root->comms.clear();
+      return give_up(std::string("ncclCommInitAll: ") + r.GetErrorString(nrc));
+    }
+    root->reduce_path = RT_REDUCE_RCCL;
   }
+  if (getenv("MI355RT_DEBUG"))
+    fprintf(stderr, "mi355rt: device group of %u, shares added %s\n", n,
+            root->reduce_path == RT_REDUCE_RCCL ? "by ncclReduce over the group's communicators" : "through host memory");
   *out = root;
+  return RT_OK;
+}
+
+int rt_group_info(const rt_ctx* ctx, rt_group_report* out) {
+  if (!ctx || !out) return RT_ERR_INVALID;
+  out->n_members = (uint32_t)ctx->peers.size() + 1u;
+  out->reduce_path = ctx->reduce_path;
+  out->render_ms_min = ctx->last_render_ms_min;
+  out->render_ms_max = ctx->last_render_ms_max;
+  out->reduce_ms = ctx->last_reduce_ms;
   return RT_OK;
 }
 
@@ -1647,12 +1678,24 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* scene) {
   // million spheres takes longer than rendering them.  MI355RT_DEVICE_BUILD=0 / 1: never / always.
   bool device_build = scene->n_prims >= (1u << 17);
   if (const char* e = getenv("MI355RT_DEVICE_BUILD")) device_build = atoi(e) != 0;
+  // Either device step may fail (out of memory, most likely); flatten_scene then does that step on
+  // the host.  The runtime's error state is cleared here, or the next hipGetLastError() of the
+  // upload would report the failure the fallback has just dealt with.
+  // MI355RT_FAIL_DEVICE_BUILD (bit 0: the hierarchy, bit 1: the order) makes them fail, for tests.
+  const char* fail_env = getenv("MI355RT_FAIL_DEVICE_BUILD");
+  const int fail_steps = fail_env ? atoi(fail_env) : 0;
   const WideBuild wide = [&](const std::vector<rt_bvh_node>& leaf_boxes, std::vector<rt_bvh_node>& records,
                              std::vector<uint32_t>& leaf_order, uint32_t& depth) {
-    return device_build_wide(ctx->stream, leaf_boxes, records, leaf_order, depth);
+    std::string e = (fail_steps & 1) ? std::string("device build: failure requested")
+                                     : device_build_wide(ctx->stream, leaf_boxes, records, leaf_order, depth);
+    if (!e.empty()) (void)hipGetLastError();
+    return e;
   };
   const RefOrderFn ref_order = [&](const std::vector<double>& centres, uint32_t n, std::vector<uint32_t>& order) {
-    return device_reference_order(ctx->stream, centres, n, order);
+    std::string e = (fail_steps & 2) ? std::string("device order: failure requested")
+                                     : device_reference_order(ctx->stream, centres, n, order);
+    if (!e.empty()) (void)hipGetLastError();
+    return e;
   };
   try {
     auto flat = std::make_shared<FlatScene>();
@@ -1662,14 +1705,21 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* scene) {
     return fail(ctx, RT_ERR_NOMEM, e.what());
   }
   if (!err.empty()) return fail(ctx, code, err);
-  int rc = upload_flat(ctx);
-  // the members of a device group get the same flattened scene: built once, copied to each
-  for (rt_ctx* peer : ctx->peers) {
-    if (rc != RT_OK) break;
-    peer->flat_ptr = ctx->flat_ptr;
-    rc = upload_flat(peer);
-    if (rc != RT_OK) ctx->error = "device " + std::to_string(peer->device) + ": " + peer->error;
+  // the members of a device group get the same flattened scene: built once, copied to all of
+  // them side by side (one host thread per member, as in a render)
+  std::vector<int> codes(ctx->peers.size(), RT_OK);
+  std::vector<std::thread> threads;
+  for (size_t k = 0; k < ctx->peers.size(); ++k) {
+    ctx->peers[k]->flat_ptr = ctx->flat_ptr;
+    threads.emplace_back([&, k]() { codes[k] = upload_flat(ctx->peers[k]); });
   }
+  int rc = upload_flat(ctx);
+  for (std::thread& t : threads) t.join();
+  for (size_t k = 0; k < ctx->peers.size() && rc == RT_OK; ++k)
+    if (codes[k] != RT_OK) {
+      rc = codes[k];
+      ctx->error = "device " + std::to_string(ctx->peers[k]->device) + ": " + ctx->peers[k]->error;
+    }
   return rc;
 }
 
@@ -1810,7 +1860,7 @@ static int upload_flat(rt_ctx* ctx) {
 int rt_render_f64(rt_ctx* ctx, const rt_render_params* p, double* rgb_sum, uint64_t* stats) {
   if (!ctx) return RT_ERR_INVALID;
   if (!rgb_sum) return fail(ctx, RT_ERR_INVALID, "null output");
-  if (!ctx->peers.empty())
+  if (ctx->group)
     return fail(ctx, RT_ERR_UNSUPPORTED, "rt_render_f64: a device group adds float shares (use rt_render)");
   double* accum = nullptr;
   int rc = render_into_accum(ctx, p, stats, &accum);
@@ -1863,9 +1913,11 @@ static int render_group(rt_ctx* root, const rt_render_params* p, float* d_out, u
       for (rt_ctx* c : m) c->progress_to = nullptr;
     }
   } report_to_root(members, root);
+  std::vector<double> member_ms(N, 0.0);
   auto work = [&](uint32_t k) {
     rt_ctx* m = members[k];
     auto run = [&]() -> int {
+      const auto t0 = std::chrono::steady_clock::now();
       RT_HIP(m, hipSetDevice(m->device));
       if (m->share.n < n) {
         m->share.release();
@@ -1881,6 +1933,7 @@ static int render_group(rt_ctx* root, const rt_render_params* p, float* d_out, u
       to_float_kernel<<<blocks_for(n), kBlock, 0, m->stream>>>(accum, m->share.p, n);
       RT_HIP(m, hipGetLastError());
       RT_HIP(m, hipStreamSynchronize(m->stream));
+      member_ms[k] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       return RT_OK;
     };
     codes[k] = run();
@@ -1900,23 +1953,38 @@ static int render_group(rt_ctx* root, const rt_render_params* p, float* d_out, u
       for (uint32_t k = 0; k < N; ++k) stats[i] += member_stats[k][i];
     }
   }
-  if (!root->comms.empty()) {
+  root->last_render_ms_min = *std::min_element(member_ms.begin(), member_ms.end());
+  root->last_render_ms_max = *std::max_element(member_ms.begin(), member_ms.end());
+  const auto reduce_t0 = std::chrono::steady_clock::now();
+  if (root->reduce_path == RT_REDUCE_RCCL) {
     Rccl r;
-    if (!load_rccl(root->rccl, r)) return fail(root, RT_ERR_DEVICE, "librccl lost its symbols");
+    if (root->comms.size() != N || !load_rccl(root->rccl, r))
+      return fail(root, RT_ERR_DEVICE, "the group's RCCL communicators are gone");
+    // One ncclReduce per member between ncclGroupStart and ncclGroupEnd (one thread drives every
+    // device), each on its member's stream, i.e. behind that member's share.  The bracket is
+    // closed on every path: an early return between the two would leave the group open.
+    std::string what;
     int nrc = r.GroupStart();
-    for (uint32_t k = 0; k < N && nrc == 0; ++k) {
-      RT_HIP(root, hipSetDevice(members[k]->device));
+    if (nrc != 0) return fail(root, RT_ERR_DEVICE, std::string("ncclGroupStart: ") + r.GetErrorString(nrc));
+    for (uint32_t k = 0; k < N && what.empty(); ++k) {
+      hipError_t e = hipSetDevice(members[k]->device);
+      if (e != hipSuccess) {
+        what = std::string("hipSetDevice: ") + hipGetErrorString(e);
+        break;
+      }
       nrc = r.Reduce(members[k]->share.p, k == 0 ? (void*)d_out : (void*)members[k]->share.p, n, kNcclFloat,
                      kNcclSum, 0, root->comms[k], members[k]->stream);
+      if (nrc != 0) what = std::string("ncclReduce: ") + r.GetErrorString(nrc);
     }
-    int erc = r.GroupEnd();
-    if (nrc == 0) nrc = erc;
-    if (nrc != 0) return fail(root, RT_ERR_DEVICE, std::string("ncclReduce: ") + r.GetErrorString(nrc));
-    for (uint32_t k = 0; k < N; ++k) {
-      RT_HIP(root, hipSetDevice(members[k]->device));
-      RT_HIP(root, hipStreamSynchronize(members[k]->stream));
+    const int erc = r.GroupEnd();
+    if (what.empty() && erc != 0) what = std::string("ncclGroupEnd: ") + r.GetErrorString(erc);
+    for (uint32_t k = 0; k < N && what.empty(); ++k) {
+      hipError_t e = hipSetDevice(members[k]->device);
+      if (e == hipSuccess) e = hipStreamSynchronize(members[k]->stream);
+      if (e != hipSuccess) what = std::string("after ncclReduce: ") + hipGetErrorString(e);
     }
-    RT_HIP(root, hipSetDevice(root->device));
+    (void)hipSetDevice(root->device);
+    if (!what.empty()) return fail(root, RT_ERR_DEVICE, what);
   } else {
     std::vector<float> sum(n), part(n);
     for (uint32_t k = 0; k < N; ++k) {
@@ -1929,6 +1997,7 @@ static int render_group(rt_ctx* root, const rt_render_params* p, float* d_out, u
     RT_HIP(root, hipSetDevice(root->device));
     RT_HIP(root, hipMemcpy(d_out, sum.data(), n * sizeof(float), hipMemcpyHostToDevice));
   }
+  root->last_reduce_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - reduce_t0).count();
   return RT_OK;
 }
 
@@ -1937,7 +2006,7 @@ int rt_render_device(rt_ctx* ctx, const rt_render_params* p, float* d_rgb_sum, u
   if (!d_rgb_sum) return fail(ctx, RT_ERR_INVALID, "null output");
   int rc = output_on_device(ctx, d_rgb_sum);
   if (rc != RT_OK) return rc;
-  if (!ctx->peers.empty()) return render_group(ctx, p, d_rgb_sum, stats);
+  if (ctx->group) return render_group(ctx, p, d_rgb_sum, stats);
   double* accum = nullptr;
   rc = render_into_accum(ctx, p, stats, &accum);
   if (rc != RT_OK) return rc;
@@ -1961,7 +2030,7 @@ int rt_set_progress(rt_ctx* ctx, rt_progress_fn fn, void* user) {
 int rt_render_device_noalloc(rt_ctx* ctx, const rt_render_params* p, float* d_rgb_sum) {
   if (!ctx) return RT_ERR_INVALID;
   if (!d_rgb_sum) return fail(ctx, RT_ERR_INVALID, "null output");
-  if (!ctx->peers.empty()) return fail(ctx, RT_ERR_UNSUPPORTED, "rt_render_device_noalloc: not for device groups");
+  if (ctx->group) return fail(ctx, RT_ERR_UNSUPPORTED, "rt_render_device_noalloc: not for device groups");
   int rc = output_on_device(ctx, d_rgb_sum);
   if (rc != RT_OK) return rc;
   double* accum = nullptr;
@@ -1989,7 +2058,7 @@ static int ensure_staging(rt_ctx* ctx, size_t bytes) {
 int rt_render(rt_ctx* ctx, const rt_render_params* p, float* rgb_sum, uint64_t* stats) {
   if (!ctx) return RT_ERR_INVALID;
   if (!rgb_sum) return fail(ctx, RT_ERR_INVALID, "null output");
-  if (!ctx->peers.empty()) {
+  if (ctx->group) {
     if (!p) return fail(ctx, RT_ERR_INVALID, "null params");
     PassInfo gps{};
     int grc = check_window(ctx, p->width, p->height, &p->window, gps);
@@ -2039,10 +2108,11 @@ int rt_first_hit(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_window* 
     });
   });
   RT_HIP(ctx, hipGetLastError());
+  // the three results follow the kernel on its stream; one wait for all of them
+  RT_HIP(ctx, hipMemcpyAsync(id, d_id, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  RT_HIP(ctx, hipMemcpyAsync(t, d_t, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  RT_HIP(ctx, hipMemcpyAsync(normal, d_n, n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  RT_HIP(ctx, hipMemcpy(id, d_id, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-  RT_HIP(ctx, hipMemcpy(t, d_t, n * sizeof(double), hipMemcpyDeviceToHost));
-  RT_HIP(ctx, hipMemcpy(normal, d_n, n * 3 * sizeof(double), hipMemcpyDeviceToHost));
   return RT_OK;
 }
 

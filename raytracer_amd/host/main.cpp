@@ -93,14 +93,31 @@ int main(int argc, char** argv) {
     else if (a == "--progress") progress = true;
     else if (a == "--no-progress") progress = false;
     else if (a == "--gpus") {
-      int n = std::atoi(next("--gpus"));
+      char* end = nullptr;
+      const char* v = next("--gpus");
+      long n = std::strtol(v, &end, 10);
+      if (end == v || *end || n < 1 || n > 64) {
+        std::fprintf(stderr, "error: --gpus wants a count from 1 to 64, not '%s'\n", v);
+        return 2;
+      }
       devices.clear();
-      for (int k = 0; k < n; ++k) devices.push_back(k);
+      for (long k = 0; k < n; ++k) devices.push_back((int32_t)k);
     } else if (a == "--devices") {
       devices.clear();
-      for (const char* c = next("--devices"); *c;) {
-        devices.push_back((int32_t)std::strtol(c, const_cast<char**>(&c), 10));
-        if (*c == ',') ++c;
+      const char* v = next("--devices");
+      for (const char* c = v; *c;) {
+        char* end = nullptr;
+        long d = std::strtol(c, &end, 10);
+        if (end == c || d < 0 || (*end && *end != ',') || (*end == ',' && !end[1])) {
+          std::fprintf(stderr, "error: --devices wants ordinals separated by commas, not '%s'\n", v);
+          return 2;
+        }
+        devices.push_back((int32_t)d);
+        c = *end == ',' ? end + 1 : end;
+      }
+      if (devices.empty()) {
+        std::fprintf(stderr, "error: --devices wants at least one ordinal\n");
+        return 2;
       }
     }
     else if (a == "-h" || a == "--help") {
@@ -154,6 +171,11 @@ int main(int argc, char** argv) {
     std::fprintf(stderr, "Error: %s\n", rt_last_error(ctx));
     return 1;
   }
+  rt_group_report group{};
+  rt_group_info(ctx, &group);
+  if (group.reduce_path != RT_REDUCE_NONE)
+    std::fprintf(stderr, "%u devices, shares added %s\n", group.n_members,
+                 group.reduce_path == RT_REDUCE_RCCL ? "by one RCCL reduce" : "through host memory");
   auto start = std::chrono::steady_clock::now();  // the reference's clock starts after loading
   std::vector<double> sum((size_t)w * h * 3);
   rt_render_params p{};
@@ -168,7 +190,7 @@ int main(int argc, char** argv) {
     rt_set_progress(ctx, draw_bar, &bar);
     draw_bar(&bar, 0, 1);
   }
-  if (devices.size() > 1) {  // a device group adds float shares
+  if (group.reduce_path != RT_REDUCE_NONE) {  // a device group adds float shares
     std::vector<float> fsum(sum.size());
     if (rt_render(ctx, &p, fsum.data(), nullptr) != RT_OK) {
       std::fprintf(stderr, "Error: %s\n", rt_last_error(ctx));
@@ -183,6 +205,9 @@ int main(int argc, char** argv) {
     rt_set_progress(ctx, nullptr, nullptr);
     std::fputc('\n', stderr);
   }
+  if (group.reduce_path != RT_REDUCE_NONE && rt_group_info(ctx, &group) == RT_OK)
+    std::fprintf(stderr, "members rendered %.1f to %.1f ms, reduce %.1f ms\n", group.render_ms_min,
+                 group.render_ms_max, group.reduce_ms);
   if (!pfm.empty()) {  // PFM rows run bottom to top; a negative scale means little-endian
     FILE* f = std::fopen(pfm.c_str(), "wb");
     if (!f) {

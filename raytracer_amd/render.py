@@ -95,6 +95,13 @@ class Context:
         self._progress = abi.ProgressFn((lambda user, done, total: fn(done, total))) if fn else abi.ProgressFn()
         self._check(abi.device_lib().rt_set_progress(self._h, self._progress, None))
 
+    def group_info(self):
+        """(members, "none" | "rccl" | "host-staged", {render_ms_min, render_ms_max, reduce_ms} of the last render)."""
+        r = abi.GroupReport()
+        self._check(abi.device_lib().rt_group_info(self._h, C.byref(r)))
+        return r.n_members, abi.REDUCE_PATHS[r.reduce_path], {
+            "render_ms_min": r.render_ms_min, "render_ms_max": r.render_ms_max, "reduce_ms": r.reduce_ms}
+
     def first_hit(self, width, height, window=None):
         L = abi.device_lib()
         w = abi.Window(*window) if window is not None else abi.Window(0, 0, 0, 0)

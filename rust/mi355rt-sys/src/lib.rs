@@ -252,6 +252,22 @@ const _: () = assert!(size_of::<rt_render_params>() == 48);
 const _: () = assert!(size_of::<rt_bvh_node>() == 32);
 const _: () = assert!(size_of::<rt_bvh_item>() == 16);
 
+/// `rt_reduce_path`: how a context adds its members' shares.
+pub const RT_REDUCE_NONE: u32 = 0;
+pub const RT_REDUCE_RCCL: u32 = 1;
+pub const RT_REDUCE_HOST_STAGED: u32 = 2;
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct rt_group_report {
+    pub n_members: u32,
+    pub reduce_path: u32,
+    pub render_ms_min: f64,
+    pub render_ms_max: f64,
+    pub reduce_ms: f64,
+}
+const _: () = assert!(size_of::<rt_group_report>() == 32);
+
 pub enum rt_ctx {}
 pub enum rt_bvh {}
 pub enum rt_host_scene {}
@@ -289,6 +305,7 @@ extern "C" {
     pub fn rt_render_device(ctx: *mut rt_ctx, p: *const rt_render_params, d_rgb_sum: *mut f32, stats: *mut u64) -> c_int;
     pub fn rt_render_device_noalloc(ctx: *mut rt_ctx, p: *const rt_render_params, d_rgb_sum: *mut f32) -> c_int;
     pub fn rt_set_progress(ctx: *mut rt_ctx, f: rt_progress_fn, user: *mut c_void) -> c_int;
+    pub fn rt_group_info(ctx: *const rt_ctx, out: *mut rt_group_report) -> c_int;
     pub fn rt_first_hit(ctx: *mut rt_ctx, width: u32, height: u32, window: *const rt_window, id: *mut u32,
                         t: *mut f64, normal: *mut f64) -> c_int;
     pub fn rt_bvh_build(scene: *const rt_scene, out: *mut *mut rt_bvh) -> c_int;

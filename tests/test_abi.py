@@ -195,7 +195,8 @@ def test_rust_mirror_follows_the_header():
               "rt_object": abi.Object, "rt_material": abi.Material, "rt_texture": abi.Texture,
               "rt_perlin": abi.Perlin, "rt_image": abi.Image, "rt_scene": abi.Scene,
               "rt_host_options": abi.HostOptions, "rt_config": abi.Config, "rt_window": abi.Window,
-              "rt_render_params": abi.RenderParams, "rt_bvh_node": abi.BvhNode, "rt_bvh_item": abi.BvhItem}
+              "rt_render_params": abi.RenderParams, "rt_bvh_node": abi.BvhNode, "rt_bvh_item": abi.BvhItem,
+              "rt_group_report": abi.GroupReport}
     for name, cls in mirror.items():
         body = re.search(r"pub struct %s \{(.*?)\n\}" % name, text, re.S).group(1)
         fields = re.findall(r"pub (\w+):", body)

@@ -65,6 +65,68 @@ def test_group_of_one_device_is_the_plain_context(gpu_ctx, golden_dir):
         one.close()
 
 
+def test_group_of_one_runs_the_rccl_reduce(gpu_ctx, golden_dir, monkeypatch):
+    """MI355RT_FORCE_RCCL=1: a group of one member with a one-rank communicator.  Everything the
+    multi-GPU reduce consists of runs on a single GPU: the run-time lookup of librccl and its six
+    entry points, ncclCommInitAll, ncclGroupStart / ncclReduce(float32, sum) on the member's
+    stream / ncclGroupEnd, the waits, ncclCommDestroy.  A one-rank sum is the share itself."""
+    import torch
+    w, h, spp = 320, 180, 5
+    scene = _scene(golden_dir, "book_cover", w, h)
+    gpu_ctx.upload(scene)
+    assert gpu_ctx.group_info()[:2] == (1, "none")
+    want, st = gpu_ctx.render(gpu_ctx.params(w, h, 0, spp, scene.max_depth, seed=4), dtype=np.float32, stats=True)
+    monkeypatch.setenv("MI355RT_FORCE_RCCL", "1")
+    one = Context(devices=[0])
+    try:
+        assert one.group_info()[:2] == (1, "rccl")
+        one.upload(scene)
+        for _ in range(2):  # the communicator serves call after call
+            got, gst = one.render(one.params(w, h, 0, spp, scene.max_depth, seed=4), dtype=np.float32, stats=True)
+            assert np.array_equal(got, want) and list(gst[:20]) == list(st[:20])
+        out = torch.full((h, w, 3), -1.0, dtype=torch.float32, device="cuda:0")
+        one.render_into(one.params(w, h, 0, spp, scene.max_depth, seed=4), out.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), want)
+        n, path, ms = one.group_info()
+        assert ms["render_ms_max"] >= ms["render_ms_min"] > 0.0 and ms["reduce_ms"] > 0.0
+        with pytest.raises(abi.RtError):  # a group adds float shares
+            one.render(one.params(w, h, 0, spp, scene.max_depth, seed=4), dtype=np.float64)
+    finally:
+        one.close()
+
+
+def test_group_says_how_it_adds_its_shares(golden_dir, monkeypatch):
+    """Two shares on one device can have no communicator (host-staged, and says so); distinct
+    devices use RCCL, or fail loudly without it unless the staged path is asked for."""
+    import torch
+    rehearsal = Context(devices=[0, 0])
+    try:
+        assert rehearsal.group_info()[:2] == (2, "host-staged")
+    finally:
+        rehearsal.close()
+    if torch.cuda.device_count() < 2:
+        return
+    w, h, spp = 160, 90, 6
+    scene = _scene(golden_dir, "book_cover", w, h)
+    single = Context(device=0)
+    try:
+        single.upload(scene)
+        lo = single.render(single.params(w, h, 0, 3, 50, seed=6), dtype=np.float32)
+        hi = single.render(single.params(w, h, 3, spp, 50, seed=6), dtype=np.float32)
+    finally:
+        single.close()
+    for staged in ("0", "1"):
+        monkeypatch.setenv("MI355RT_STAGED_REDUCE", staged)
+        pair = Context(devices=[0, 1])
+        try:
+            assert pair.group_info()[:2] == (2, "host-staged" if staged == "1" else "rccl")
+            pair.upload(scene)
+            assert np.array_equal(pair.render(pair.params(w, h, 0, spp, 50, seed=6), dtype=np.float32), lo + hi)
+        finally:
+            pair.close()
+
+
 def test_sharded_render_into_a_device_tensor(gpu_ctx, golden_dir):
     """render_sharded with the device render (one rank): the tensor holds the whole range's sums."""
     import torch

@@ -230,6 +230,22 @@ def test_device_built_hierarchy_gives_the_host_built_results(gpu_ctx, golden_dir
         assert np.array_equal(out["1"][0], rid) and np.array_equal(out["1"][1], rt_)
 
 
+@pytest.mark.parametrize("steps", ["1", "2", "3"])
+def test_failed_device_build_falls_back_to_the_host(gpu_ctx, monkeypatch, steps):
+    """Either device step of the upload may fail (bit 0: the hierarchy, bit 1: the reference's
+    order); the host then does that step and the upload succeeds with the same results."""
+    scene = HostScene.generate_cover(30, scene_seed=9, width=128, height=72, spp=2, max_depth=8)
+    w, h = scene.width, scene.height
+    monkeypatch.setenv("MI355RT_DEVICE_BUILD", "0")
+    gpu_ctx.upload(scene)
+    want = (gpu_ctx.first_hit(w, h)[0], gpu_ctx.render(gpu_ctx.params(w, h, 0, 2, 8, seed=3), dtype=np.float64))
+    monkeypatch.setenv("MI355RT_DEVICE_BUILD", "1")
+    monkeypatch.setenv("MI355RT_FAIL_DEVICE_BUILD", steps)
+    gpu_ctx.upload(scene)
+    assert np.array_equal(gpu_ctx.first_hit(w, h)[0], want[0])
+    assert np.array_equal(gpu_ctx.render(gpu_ctx.params(w, h, 0, 2, 8, seed=3), dtype=np.float64), want[1])
+
+
 def test_stats_match_flat_oracle(gpu_ctx, golden_dir):
     """The device walks the flattened BVH exactly as the instrumented CPU traversal does."""
     from raytracer_amd.render import build_bvh

@@ -286,3 +286,15 @@ def test_frozen_scene_with_a_corrupted_header_is_refused_cleanly(tmp_path):
     finally:
         resource.setrlimit(resource.RLIMIT_AS, (soft, hard))
     assert refused >= 8 and refused + loaded == len(range(0, min(len(raw) - 4, 800), 4))
+
+
+@pytest.mark.parametrize("args", [["--devices", "0,x"], ["--devices", "a"], ["--devices", "0,"], ["--devices", ""],
+                                  ["--gpus", "0"], ["--gpus", "-3"], ["--gpus", "two"]])
+def test_cli_rejects_malformed_device_lists(args):
+    """A device list that is not ordinals separated by commas, or a count below one, ends with the
+    usage error (exit status 2) before anything is loaded."""
+    import subprocess
+    from raytracer_amd import abi
+    exe = os.path.join(abi.LIB_DIR, "raytracer")
+    r = subprocess.run([exe, "no_such_scene.ron"] + args, capture_output=True, text=True, timeout=20)
+    assert r.returncode == 2 and "error:" in r.stderr
