@@ -185,6 +185,56 @@ RT_DEV LiveIn live_in(const PathBuffers& pb, uint32_t bounce, uint32_t n_paths) 
   return li;
 }
 
+// The same live paths as trips of 64 for trace_kernel: the index space gives every sub-queue a
+// whole number of trips (its count rounded up to 64), so a trip lies in one sub-queue and which
+// one is settled with scalar arithmetic on the trip's first index; the lanes past the end of a
+// sub-queue's last trip get no path.  (Finding the sub-queue per lane, through eight compares
+// and selects against prefix sums, was forty vector instructions of every trip.)
+const uint32_t kNoPath = 0xFFFFFFFFu;  // (a pass holds at most 2^30 paths)
+struct LiveTrips {
+  uint32_t count[kSubQueues];  // entries per sub-queue (bounce 0: unused)
+  const uint32_t* queue;
+  uint64_t capacity;
+  uint32_t n_paths;   // bounce 0: every path of the pass, in order
+  uint32_t end;       // end of the trip index space
+  // Path of lane `lane` in the trip that starts at index `base` (wave-uniform, a multiple of 64), or kNoPath.
+  template <bool IDENTITY>
+  RT_DEV uint32_t fetch(uint32_t base, uint32_t lane) const {
+    if (IDENTITY) {
+      const uint32_t i = base + lane;
+      return i < n_paths ? i : kNoPath;
+    }
+    uint32_t off = base, q = 0;
+#pragma unroll
+    for (uint32_t k = 0; k + 1 < kSubQueues; ++k) {
+      const uint32_t padded = (count[k] + 63u) & ~63u;
+      const bool past = q == k && off >= padded;
+      off = past ? off - padded : off;
+      q = past ? k + 1u : q;
+    }
+    uint32_t cnt = count[0];
+#pragma unroll
+    for (uint32_t k = 1; k < kSubQueues; ++k) cnt = q == k ? count[k] : cnt;
+    const uint32_t j = off + lane;
+    return j < cnt ? queue[(size_t)q * capacity + j] : kNoPath;
+  }
+};
+RT_DEV LiveTrips live_trips(const PathBuffers& pb, uint32_t bounce, uint32_t n_paths) {
+  LiveTrips lt;
+  lt.queue = pb.live[bounce & 1u];
+  lt.capacity = pb.capacity;
+  lt.n_paths = n_paths;
+  const uint32_t* row = pb.counters + (size_t)(bounce == 0 ? 0u : bounce - 1u) * kCounterStride;
+  uint32_t end = 0;
+#pragma unroll
+  for (uint32_t q = 0; q < kSubQueues; ++q) {
+    lt.count[q] = bounce == 0 ? 0u : row[32u * (1u + q)];
+    end += (lt.count[q] + 63u) & ~63u;
+  }
+  lt.end = bounce == 0 ? ((n_paths + 63u) & ~63u) : end;
+  return lt;
+}
+
 // Queue appends are staged in LDS.  A returning atomic on one global word
 // saturates near 90 per microsecond on this chip, far below one per wave per
 // bin, so a workgroup collects entries in an LDS buffer (slots handed out by an
@@ -353,10 +403,12 @@ extend_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32
 // material kind `kind` (src/material/*.rs, src/texture/isotropic.rs).
 struct ShadeOut {
   V3 attenuation, direction, emitted, p;
-  double fuzz;      // metal: scale of the random vector
+  V3 alt;           // dielectric whose choice is still open: the refracted direction (`direction`: the mirrored one)
+  double fuzz;      // metal: scale of the random vector; open dielectric: reflect iff fuzz > the uniform
   uint32_t kind;
   bool scattered, emits;
   bool needs_vector;  // direction still lacks its random unit vector (shade_finish)
+  bool needs_u;       // dielectric: the reflect-or-refract uniform is still to be drawn (shade_finish)
 };
 
 // First half: everything up to the material's random unit vector.  For Lambertian,
@@ -368,7 +420,11 @@ RT_DEV uint32_t material_of(const DPrim& pr) {
 
 // SOLID: the material's texture (if it has one) is known to be a SolidColor, whose colour the
 // material record carries: no texture walk, no (u, v).
-template <bool STATS, bool SOLID>
+// SPHERES: `pr` is a plain sphere without wrappers.
+// LATER: a Dielectric hit leaves its uniform draw to the caller (needs_u; both directions are
+// prepared and shade_finish picks), so that the draw can share a generator block's trip with the
+// wave's random vectors.
+template <bool STATS, bool SOLID, bool SPHERES = false, bool LATER = false>
 RT_DEV ShadeOut shade_begin(const DeviceScene& sc, uint32_t kind, const DPrim& pr, uint32_t material,
                             V3 o, V3 d, double time, double t, const DrawKey& key, Stats& st) {
   ShadeOut out;
@@ -380,12 +436,14 @@ RT_DEV ShadeOut shade_begin(const DeviceScene& sc, uint32_t kind, const DPrim& p
   out.scattered = false;
   out.emits = false;
   out.needs_vector = false;
+  out.needs_u = false;
+  out.alt = v3(0.0, 0.0, 0.0);
   stat<STATS>(st, RT_STAT_SHADE_LAMBERTIAN + (int)kind);
   const DMaterial m = sc.materials[material];
   const bool textured = kind == RT_MAT_LAMBERTIAN || kind == RT_MAT_DIFFUSE_LIGHT ||
                         kind == RT_MAT_ISOTROPIC;
   bool want_uv = textured && ((pr.kind >> 11) & 1u);
-  Record rec = make_record<!SOLID>(sc, pr, o, d, time, t, want_uv);
+  Record rec = make_record<!SOLID, SPHERES>(sc, pr, o, d, time, t, want_uv);
   out.p = rec.p;
   // Metal and Dielectric both start from the unit direction and its mirror image; a wave that
   // holds both kinds computes them in one go instead of once per branch.
@@ -412,9 +470,16 @@ RT_DEV ShadeOut shade_begin(const DeviceScene& sc, uint32_t kind, const DPrim& p
     double cos_theta = fmin(vdot(vneg(ud), rec.normal), 1.0);
     double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
     bool cannot_refract = ratio * sin_theta > 1.0;
-    u32x4 fb = draw(key, DRAW_FRESNEL, 0);
-    bool should_reflect = reflectance(cos_theta, ratio) > u01_53(fb.x, fb.y);
-    out.direction = (cannot_refract || should_reflect) ? mirrored : vrefract(ud, rec.normal, ratio);
+    if (LATER) {
+      out.direction = mirrored;
+      out.alt = vrefract(ud, rec.normal, ratio);
+      out.fuzz = cannot_refract ? 2.0 : reflectance(cos_theta, ratio);  // (2 > every uniform: reflect)
+      out.needs_u = true;
+    } else {
+      u32x4 fb = draw(key, DRAW_FRESNEL, 0);
+      bool should_reflect = reflectance(cos_theta, ratio) > u01_53(fb.x, fb.y);
+      out.direction = (cannot_refract || should_reflect) ? mirrored : vrefract(ud, rec.normal, ratio);
+    }
     out.attenuation = v3(1.0, 1.0, 1.0);
     out.scattered = true;
   } else if (kind == RT_MAT_DIFFUSE_LIGHT) {  // emissive.rs:10-12; never scatters
@@ -428,8 +493,10 @@ RT_DEV ShadeOut shade_begin(const DeviceScene& sc, uint32_t kind, const DPrim& p
   return out;
 }
 
-// Second half: `inside` is the accepted candidate of rand_unit_vector's rejection loop.
-RT_DEV void shade_finish(ShadeOut& out, V3 inside) {
+// Second half: `inside` is the accepted candidate of rand_unit_vector's rejection loop, `u` the
+// uniform of an open Dielectric choice.
+RT_DEV void shade_finish(ShadeOut& out, V3 inside, double u = 0.0) {
+  if (out.needs_u && !(out.fuzz > u)) out.direction = out.alt;
   if (!out.needs_vector) return;
   const V3 ruv = vunit(inside);
   if (out.kind == RT_MAT_LAMBERTIAN) {
@@ -479,6 +546,7 @@ shade_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps, uint32_t bounce, uint3
     DrawKey key{ps.seed, 0u, 0u, bounce};
     ShadeOut so;
     so.needs_vector = false;
+    so.needs_u = false;
     if (valid) {
       path = queue[i];
       double4 bt = pb.beta[path];
@@ -511,7 +579,7 @@ shade_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps, uint32_t bounce, uint3
         if (survives) {
           // everything but the direction is known before the random vector
           V3 nb = vmul(beta, so.attenuation);
-          pb.beta[path] = make_double4(nb.x, nb.y, nb.z, 0.0);
+          pb.beta[path] = make_double4(nb.x, nb.y, nb.z, bt.w);  // (.w: the path's pixel and sample, see trace_kernel)
           pb.ray_o[path] = make_double4(so.p.x, so.p.y, so.p.z, ro.w);
         } else if (BIN == kAnyBin && !sc.has_lights) {
           // the fused kernel leaves L unwritten until a path ends when nothing emits
@@ -597,23 +665,31 @@ enum { kTraceBounce = 0, kTraceTail = 1, kTraceFirst = 2 };
 constexpr int trace_waves_per_simd(int block, bool stats, bool media) {
   return stats ? (block >= 512 ? 2 : 1) : media ? RT_TRACE_MEDIA_WAVES : 4;
 }
-template <int BLOCK, bool STATS, bool MEDIA, bool OVERFLOW, int MODE>
+// SPHERES: every leaf slot of the scene is a plain sphere without wrappers and nothing is deferred
+// (the reference's book_cover.ron and its scale-ups): the leaf test, the hit record and the
+// workgroup's copy of the leaf slots (32 bytes each instead of 48) carry that one case only.
+// The pixel and sample a path belongs to (the address of its draws) ride in the spare word of
+// its attenuation, written by the first bounce: the variants without media read them back after
+// the walk instead of deriving them from the path index again on every bounce.
+template <int BLOCK, bool STATS, bool MEDIA, bool OVERFLOW, int MODE, bool SPHERES = false>
 __global__ void __launch_bounds__(BLOCK, trace_waves_per_simd(BLOCK, STATS, MEDIA))
 trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_t first_bounce_arg,
              uint32_t max_depth, unsigned long long* g_stats) {
+  static_assert(!(MEDIA && SPHERES), "the sphere-only variant carries no media");
   constexpr bool TAIL = MODE == kTraceTail, FIRST = MODE == kTraceFirst;
+  constexpr bool KEY_FROM_PATH = FIRST || MEDIA;  // else from the path's attenuation record
   const uint32_t first_bounce = FIRST ? 0u : first_bounce_arg;
   extern __shared__ __align__(16) char smem[];
   __shared__ uint32_t s_next[(BLOCK / 64) * kWaveStage];
   constexpr bool DEFER = !TAIL;  // (the tail shades everything in place; the host runs none for textured scenes)
   __shared__ uint32_t s_defer[DEFER ? (BLOCK / 64) * kDeferStage : 1];
-  const LiveIn live = live_in(pb, first_bounce, ps.n_paths);  // (bounce 0: no queue, path = index)
+  const LiveTrips live = live_trips(pb, first_bounce, ps.n_paths);  // (bounce 0: no queue, path = index)
   uint32_t* next_live = next_live_queue(pb, first_bounce, blockIdx.x);
   uint32_t* next_count = next_live_counter(pb, first_bounce, blockIdx.x);
   uint32_t* counters = pb.counters + (size_t)first_bounce * kCounterStride;
-  const uint32_t n_live = live.total();
+  const uint32_t n_live = live.end;  // (of the trip index space: see LiveTrips)
   if (blockIdx.x * (uint32_t)BLOCK >= n_live) return;
-  const LdsScene lds = lds_stage(sc, lay, smem, threadIdx.x, BLOCK);  // the only workgroup barrier
+  const LdsScene lds = lds_stage<SPHERES ? 2u : 3u>(sc, lay, smem, threadIdx.x, BLOCK);  // the only workgroup barrier
   sc.ops_lds_offset = lds.ops_offset;
   sc.n_ops_lds = lay.n_ops;
   uint32_t* stage = s_next + (threadIdx.x / 64u) * kWaveStage;
@@ -643,25 +719,18 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
     return ((((r >> kRunLog) * kTripsPerGrab) << kRunLog) + (r & ((1u << kRunLog) - 1u))) * 64u;
   };
   constexpr uint32_t kTripStep = 64u << kRunLog;  // from one trip of a run to its next
-  uint32_t base = TAIL ? blockIdx.x * (uint32_t)BLOCK + (threadIdx.x & ~63u) : draw_run();
+  uint32_t base = TAIL ? (uint32_t)__builtin_amdgcn_readfirstlane(
+                             (int)(blockIdx.x * (uint32_t)BLOCK + (threadIdx.x & ~63u)))
+                       : draw_run();
   uint32_t trip_in_run = 0;
-  uint32_t path_ahead = 0;
-  {
-    const uint32_t first_i = base + (threadIdx.x & 63u);
-    path_ahead = FIRST ? first_i : first_i < n_live ? live.path(first_i) : 0u;
-  }
+  uint32_t path_ahead = live.template fetch<FIRST>(base, threadIdx.x & 63u);
   while (base < n_live) {
-    const uint32_t i = base + (threadIdx.x & 63u);
-    bool valid = i < n_live;
     uint32_t path = path_ahead;
+    bool valid = path != kNoPath;
     // where the next trip starts, when that is known already
     uint32_t next_base = TAIL ? base + stride : base + kTripStep, next_trip = trip_in_run + 1u;
     const bool draws = !TAIL && (next_trip == kTripsPerGrab || next_base >= n_live);
-    if (!draws) {
-      const uint32_t ni = next_base + (threadIdx.x & 63u);
-      if (FIRST) path_ahead = ni;
-      else if (ni < n_live && next_base > base) path_ahead = live.path(ni);
-    }
+    if (!draws && next_base > base) path_ahead = live.template fetch<FIRST>(next_base, threadIdx.x & 63u);
     uint32_t bounce = first_bounce;
     bool survives, deferred = false;
     do {
@@ -672,12 +741,15 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
       DrawKey key{ps.seed, 0u, 0u, bounce};
       ShadeOut so;
       so.needs_vector = false;
+      so.needs_u = false;
       if (valid) {
-        uint32_t s_local = fastdiv(path, ps.by_pixels), local = path - s_local * ps.n_pixels;
-        uint32_t x, y;
-        pixel_of(ps, local, x, y);
-        key.pixel = y * ps.width + x;
-        key.sample = ps.sample_base + s_local;
+        uint32_t x = 0, y = 0;
+        if (KEY_FROM_PATH) {
+          uint32_t s_local = fastdiv(path, ps.by_pixels), local = path - s_local * ps.n_pixels;
+          pixel_of(ps, local, x, y);
+          key.pixel = y * ps.width + x;
+          key.sample = ps.sample_base + s_local;
+        }
         V3 o, d;
         double time;
         // the first bounce makes its own camera ray
@@ -693,30 +765,21 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
         stat<STATS>(st, RT_STAT_RAYS);
         RT_LP(st, LP_RAY);
         RT_TICK(st, LP_T_SETUP, tick);
-#if defined(RT_DBG_NO_TRAVERSE)
-        Closest h;
-        if (MODE == kTraceBounce) {
-          h.item = path % 488u;
-          h.t = 1.0;
-          h.kind = sc.prims[h.item].kind;
-        } else {
-          h = closest_hit<STATS, MEDIA, MEDIA, OVERFLOW>(sc, lds, o, d, time, 0.001, key, st);
-        }
-#else
-        Closest h = closest_hit<STATS, MEDIA, MEDIA, OVERFLOW>(sc, lds, o, d, time, 0.001, key, st);
-#endif
-#if defined(RT_DBG_NO_SHADE)
-        if (MODE == kTraceBounce) {
-          if (h.item != kNoPrim && h.t == 12345.0) pb.radiance[path] = make_double4(h.t, 0.0, 0.0, 0.0);
-          h.item = kNoPrim;
-        }
-#endif
+        Closest h = closest_hit<STATS, MEDIA, MEDIA, OVERFLOW, SPHERES>(sc, lds, o, d, time, 0.001, key, st);
         RT_TICK(st, LP_T_TRAVERSE, tick);
         // ... and starts from beta = 1, L = 0
         V3 beta = v3(1.0, 1.0, 1.0);
+        double tag;  // (pixel, sample) as the spare word of the attenuation record keeps them
         if (!FIRST) {
           double4 bt = pb.beta[path];
           beta = v3(bt.x, bt.y, bt.z);
+          tag = bt.w;
+          if (!KEY_FROM_PATH) {
+            key.pixel = (uint32_t)__double2loint(tag);
+            key.sample = (uint32_t)__double2hiint(tag);
+          }
+        } else {
+          tag = __hiloint2double((int)key.sample, (int)key.pixel);
         }
         V3 add = v3(0.0, 0.0, 0.0);
         bool adds = false;
@@ -725,20 +788,27 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
           stat<STATS>(st, RT_STAT_SHADE_MISS);
           add = vmul(beta, v3(sc.bg));
           adds = true;
-        } else if (DEFER && (h.kind & kDeferBit)) {
+        } else if (!SPHERES && DEFER && (h.kind & kDeferBit)) {
           stat<STATS>(st, RT_STAT_HITS);
           deferred = true;
           pb.ray_o[path] = make_double4(o.x, o.y, o.z, time);
           pb.ray_d[path] = make_double4(d.x, d.y, d.z, h.t);
           pb.hit_item[path] = h.item;
-          if (FIRST) pb.beta[path] = make_double4(1.0, 1.0, 1.0, 0.0);
+          if (FIRST) pb.beta[path] = make_double4(1.0, 1.0, 1.0, tag);
         } else {
           stat<STATS>(st, RT_STAT_HITS);
           RT_LP(st, LP_SHADE);
-          // (the cold quarter of the record only where something reads it)
-          const bool whole = (h.kind & kMaterialElsewhereBit) != 0u;
-          const DPrim pr = whole ? load_prim<true>(sc, lds, h.item) : load_prim<false>(sc, lds, h.item);
-          so = shade_begin<STATS, true>(sc, (h.kind >> 8) & 7u, pr, material_of(pr), o, d, time, h.t, key, st);
+          DPrim pr;
+          if (SPHERES) {
+            pr = sc.prims[h.item];  // (the workgroup's copy holds centre and radius only)
+            h.kind = pr.kind;
+          } else {
+            // (the cold quarter of the record only where something reads it)
+            const bool whole = (h.kind & kMaterialElsewhereBit) != 0u;
+            pr = whole ? load_prim<true>(sc, lds, h.item) : load_prim<false>(sc, lds, h.item);
+          }
+          so = shade_begin<STATS, true, SPHERES, true>(sc, (h.kind >> 8) & 7u, pr, material_of(pr), o, d, time, h.t,
+                                                       key, st);
           if (so.emits) {
             add = vmul(beta, so.emitted);
             adds = true;
@@ -748,7 +818,7 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
           if (survives) {
             // everything but the direction is known before the random vector
             V3 nb = vmul(beta, so.attenuation);
-            pb.beta[path] = make_double4(nb.x, nb.y, nb.z, 0.0);
+            pb.beta[path] = make_double4(nb.x, nb.y, nb.z, tag);
             pb.ray_o[path] = make_double4(so.p.x, so.p.y, so.p.z, time);
           }
         }
@@ -767,18 +837,13 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
         }
       }
       RT_TICK(st, LP_T_SHADE, tick);
-      {  // whole waves: the lanes look for their random vectors together
+      {  // whole waves: the lanes look for their random vectors (and uniforms) together
         // (the wave's part of the first two stack rows is idle between traversals)
-#if defined(RT_DBG_NO_VECTOR)
-        V3 inside = MODE == kTraceBounce ? v3(0.3, 0.4, 0.5)
-                                         : wave_rand_in_unit_sphere(survives && so.needs_vector, key,
-                                                                    lds.stack - (threadIdx.x & 63u), BLOCK, st);
-#else
-        V3 inside = wave_rand_in_unit_sphere(survives && so.needs_vector, key,
-                                             lds.stack - (threadIdx.x & 63u), BLOCK, st);
-#endif
+        double u = 0.0;
+        V3 inside = wave_rand_in_unit_sphere(survives && so.needs_vector, survives && so.needs_u, key,
+                                             lds.stack - (threadIdx.x & 63u), BLOCK, st, u);
         RT_TICK(st, LP_T_VECTOR, tick);
-        shade_finish(so, inside);
+        shade_finish(so, inside, u);
       }
       if (survives)
         pb.ray_d[path] = make_double4(so.direction.x, so.direction.y, so.direction.z, 0.0);
@@ -814,9 +879,7 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
     if (draws) {
       next_base = draw_run();
       next_trip = 0;
-      const uint32_t ni = next_base + (threadIdx.x & 63u);
-      if (FIRST) path_ahead = ni;
-      else if (ni < n_live) path_ahead = live.path(ni);
+      path_ahead = live.template fetch<FIRST>(next_base, threadIdx.x & 63u);
     }
     if (TAIL && next_base <= base) break;  // (32-bit wrap at the very end of the index range)
     base = next_base;
@@ -1000,6 +1063,7 @@ struct rt_ctx {
   uint32_t pb_queues = 0;  // bin queues allocated in pb.bins
   bool solid = true;       // every texture is a SolidColor
   bool general = false;    // the scene needs the general trace kernel
+  bool spheres = false;    // every leaf slot is a plain sphere without wrappers: the sphere-only trace kernel
   uint32_t counters_depth = 0;
   DeviceArray<double> accum;
   DeviceArray<unsigned long long> stats;
@@ -1187,12 +1251,14 @@ int check_window(rt_ctx* ctx, uint32_t width, uint32_t height, const rt_window* 
   return RT_OK;
 }
 
+uint32_t ops_count_host(uint32_t w) { return w >> 24; }
 uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); }
 
 // LDS plan for workgroups of `block` threads within `budget` bytes: the traversal
 // stack first (it is not optional), then as many top-of-tree records as fit, then
 // leaf slots with what is left.
-LdsLayout plan_lds(const FlatScene& f, uint32_t block, uint32_t budget, uint32_t stack_cap) {
+LdsLayout plan_lds(const FlatScene& f, uint32_t block, uint32_t budget, uint32_t stack_cap,
+                   uint32_t slot_bytes = kPrimHotBytes) {
   LdsLayout l{};
   // one spare entry: a visit stores before it knows whether it keeps; two rows at least: they
   // double as the exchange area of wave_rand_in_unit_sphere.  The worst-case need can be several
@@ -1214,8 +1280,8 @@ LdsLayout plan_lds(const FlatScene& f, uint32_t block, uint32_t budget, uint32_t
   // (+3: the never-hit records that end the device copy, so the last group stays in LDS)
   l.n_nodes = std::min<uint32_t>((uint32_t)f.nodes.size() + 3u, room / 32u);
   room -= l.n_nodes * 32u;
-  l.n_prims = std::min<uint32_t>((uint32_t)f.prims.size(), room / kPrimHotBytes);
-  l.bytes = used + l.n_nodes * 32u + l.n_prims * kPrimHotBytes;
+  l.n_prims = std::min<uint32_t>((uint32_t)f.prims.size(), room / slot_bytes);
+  l.bytes = used + l.n_nodes * 32u + l.n_prims * slot_bytes;
   return l;
 }
 
@@ -1232,6 +1298,20 @@ auto with_bool(bool v, F&& f) {
   return v ? f(std::true_type{}) : f(std::false_type{});
 }
 
+// The sphere-only variant: 512-thread workgroups, never together with media.
+void launch_trace_spheres(rt_ctx* ctx, bool stats, bool tail, uint32_t grid, const PathBuffers& pb,
+                          const PassInfo& ps, uint32_t b, uint32_t max_depth, unsigned long long* gs) {
+  const LdsLayout& l = ctx->lds_trace;
+  with_bool(stats, [&](auto S) {
+    return with_bool(l.overflow != nullptr, [&](auto O) {
+      return with_mode(tail ? kTraceTail : b == 0 ? kTraceFirst : kTraceBounce, [&](auto T) {
+        trace_kernel<512, decltype(S)::value, false, decltype(O)::value, decltype(T)::value, true>
+            <<<grid, 512, l.bytes, ctx->stream>>>(ctx->ds, l, pb, ps, b, max_depth, gs);
+        return 0;
+      });
+    });
+  });
+}
 template <int BLOCK>
 void launch_trace_block(rt_ctx* ctx, bool stats, bool media, bool tail, uint32_t grid,
                         const PathBuffers& pb, const PassInfo& ps, uint32_t b, uint32_t max_depth,
@@ -1252,7 +1332,8 @@ void launch_trace_block(rt_ctx* ctx, bool stats, bool media, bool tail, uint32_t
 }
 void launch_trace(rt_ctx* ctx, bool stats, bool media, bool tail, uint32_t grid, const PathBuffers& pb,
                   const PassInfo& ps, uint32_t b, uint32_t max_depth, unsigned long long* gs) {
-  if (ctx->trace_block == 512) launch_trace_block<512>(ctx, stats, media, tail, grid, pb, ps, b, max_depth, gs);
+  if (ctx->spheres) launch_trace_spheres(ctx, stats, tail, grid, pb, ps, b, max_depth, gs);
+  else if (ctx->trace_block == 512) launch_trace_block<512>(ctx, stats, media, tail, grid, pb, ps, b, max_depth, gs);
   else launch_trace_block<256>(ctx, stats, media, tail, grid, pb, ps, b, max_depth, gs);
 }
 void launch_extend(rt_ctx* ctx, bool stats, bool media, uint32_t grid, const PathBuffers& pb,
@@ -1283,6 +1364,21 @@ hipError_t allow_trace_lds(int bytes) {
                                           decltype(O)::value, decltype(T)::value>,
                 attr, bytes);
           });
+        });
+      });
+    });
+  return e;
+}
+hipError_t allow_trace_spheres_lds(int bytes) {
+  const hipFuncAttribute attr = hipFuncAttributeMaxDynamicSharedMemorySize;
+  hipError_t e = hipSuccess;
+  for (int v = 0; v < 12 && e == hipSuccess; ++v)
+    e = with_bool(v & 1, [&](auto S) {
+      return with_bool(v & 2, [&](auto O) {
+        return with_mode(v >> 2, [&](auto T) {
+          return hipFuncSetAttribute(
+              (const void*)trace_kernel<512, decltype(S)::value, false, decltype(O)::value, decltype(T)::value, true>,
+              attr, bytes);
         });
       });
     });
@@ -1814,6 +1910,12 @@ static int upload_flat(rt_ctx* ctx) {
     if (tb != 256u && tb != 512u)
       return fail(ctx, RT_ERR_INVALID, "MI355RT_TRACE_BLOCK must be 256 or 512");
     ctx->trace_block = tb;
+    // plain spheres only, nothing deferred (book_cover.ron and its scale-ups): the sphere-only kernel
+    bool spheres = !ctx->general && !f.defers && tb == 512u && !f.prims.empty();
+    for (const DPrim& pr : f.prims)
+      spheres = spheres && (pr.kind & 15u) == DP_SPHERE && ops_count_host(pr.ops) == 0u && !(pr.kind & kDeferBit);
+    if (const char* e = getenv("MI355RT_SPHERES_KERNEL")) spheres = spheres && atoi(e) != 0;  // (A/B timing)
+    ctx->spheres = spheres;
     const uint32_t per_cu = std::max(1u, (ctx->general ? 256u * RT_TRACE_MEDIA_WAVES : 1024u) / tb);  // resident
     // launched: as many workgroups as are resident together; the waves draw their work from a
     // counter, so nothing is gained by more
@@ -1825,7 +1927,7 @@ static int upload_flat(rt_ctx* ctx) {
     uint32_t tbudget = (160u * 1024u) / per_cu - stage_bytes - 1024u;
     if (const char* e = getenv("MI355RT_TRACE_LDS_BYTES")) tbudget = (uint32_t)strtoul(e, nullptr, 10);
     tbudget = std::min(tbudget, 160u * 1024u - stage_bytes - 512u);
-    ctx->lds_trace = plan_lds(f, tb, tbudget, stack_cap);
+    ctx->lds_trace = plan_lds(f, tb, tbudget, stack_cap, ctx->spheres ? 32u : kPrimHotBytes);
     // overflow area for the stack entries LDS does not hold: one column per thread of the
     // largest grid any traversal kernel is launched with
     ctx->stack_overflow.release();
@@ -1851,7 +1953,8 @@ static int upload_flat(rt_ctx* ctx) {
   if (ctx->lds.bytes > 32u * 1024u) RT_HIP(ctx, allow_extend_lds((int)ctx->lds.bytes));
   if (ctx->lds_trace.bytes > 32u * 1024u) {
     int bytes = (int)ctx->lds_trace.bytes;
-    RT_HIP(ctx, ctx->trace_block == 512 ? allow_trace_lds<512>(bytes) : allow_trace_lds<256>(bytes));
+    RT_HIP(ctx, ctx->spheres ? allow_trace_spheres_lds(bytes)
+                : ctx->trace_block == 512 ? allow_trace_lds<512>(bytes) : allow_trace_lds<256>(bytes));
   }
   ctx->have_scene = true;
   return RT_OK;

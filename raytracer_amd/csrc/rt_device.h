@@ -392,13 +392,21 @@ RT_DEV void sphere_uv(V3 n, double& u, double& v) {  // Sphere::get_uv, sphere.r
 
 // The HitRecord the reference would return for leaf slot `pr` hit at parameter t
 // by the world-frame ray (o, d, time).
-template <bool UV_POSSIBLE = true>
+// SPHERES: the record is known to be a plain sphere without wrappers.
+template <bool UV_POSSIBLE = true, bool SPHERES = false>
 RT_DEV Record make_record(const DeviceScene& sc, const DPrim& pr, V3 o, V3 d, double time, double t,
                           bool want_uv) {
   if (!UV_POSSIBLE) want_uv = false;  // no texture of the scene reads (u, v): drops acos/atan2
   Record r;
   r.u = 0.0;
   r.v = 0.0;
+  if (SPHERES) {  // sphere.rs:52-63
+    r.p = vadd(o, vscale(d, t));
+    V3 outward = vscale(vsub(r.p, v3(pr.p[0], pr.p[1], pr.p[2])), pr.p[4]);
+    if (want_uv) sphere_uv(outward, r.u, r.v);
+    set_face_normal(r, d, outward);
+    return r;
+  }
   Stats unused;
   uint32_t kind = pr.kind & 15u;
   uint32_t n_ops = ops_count(pr.ops);
@@ -461,18 +469,15 @@ RT_DEV CullAxis cull_axis(double o, double d) {
   if (!(fabsf(inv) <= 1e25f)) inv = copysignf(1e25f, d32);
   float noi = -(o32 * inv);
   float e = fabsf(noi) * 4.76837158203125e-07f;  // 2^-21
+  // which plane is the exit follows the sign of inv; the entry side's factor is exactly 1
+  const bool pos = inv >= 0.0f;
+  const float k_lo = pos ? 1.0f : kWiden, k_hi = pos ? kWiden : 1.0f;
+  const float a_entry = noi - e, a_exit = noi + e;
   CullAxis c;
-  if (inv >= 0.0f) {  // lo plane is the entry, hi plane the exit
-    c.inv_lo = inv;
-    c.add_lo = noi - e;
-    c.inv_hi = inv * kWiden;
-    c.add_hi = (noi + e) * kWiden;
-  } else {
-    c.inv_lo = inv * kWiden;
-    c.add_lo = (noi + e) * kWiden;
-    c.inv_hi = inv;
-    c.add_hi = noi - e;
-  }
+  c.inv_lo = inv * k_lo;
+  c.add_lo = (pos ? a_entry : a_exit) * k_lo;
+  c.inv_hi = inv * k_hi;
+  c.add_hi = (pos ? a_exit : a_entry) * k_hi;
   return c;
 }
 
@@ -514,17 +519,21 @@ struct LdsScene {
 
 // Carve the workgroup's dynamic LDS and stage the scene head into it.  Every
 // thread of the workgroup must call this (it ends with a barrier).
+// PRIM_QUADS: 16-byte pieces of a leaf-slot record that are staged (3: everything the traversal
+// reads of any record; 2: centre and radius, all it reads when every record is a plain sphere).
+template <uint32_t PRIM_QUADS = 3>
 RT_DEV LdsScene lds_stage(const DeviceScene& sc, const LdsLayout& lay, char* smem, uint32_t tid,
                           uint32_t block) {
   lds_f32x4* nodes = (lds_f32x4*)smem;
   lds_f32x4* prims = nodes + 2u * lay.n_nodes;
-  lds_f32x4* ops = prims + 3u * lay.n_prims;
+  lds_f32x4* ops = prims + PRIM_QUADS * lay.n_prims;
   lds_u32* stack = (lds_u32*)(ops + 2u * lay.n_ops);
   const f32x4* gn = (const f32x4*)sc.nodes;
   const f32x4* gp = (const f32x4*)sc.prims;
   const f32x4* go = (const f32x4*)sc.ops;
   for (uint32_t i = tid; i < 2u * lay.n_nodes; i += block) nodes[i] = gn[i];
-  for (uint32_t i = tid; i < 3u * lay.n_prims; i += block) prims[i] = gp[4u * (i / 3u) + i % 3u];
+  for (uint32_t i = tid; i < PRIM_QUADS * lay.n_prims; i += block)
+    prims[i] = gp[4u * (i / PRIM_QUADS) + i % PRIM_QUADS];
   for (uint32_t i = tid; i < 2u * lay.n_ops; i += block) ops[i] = go[i];
   __syncthreads();
   LdsScene l;
@@ -539,7 +548,7 @@ RT_DEV LdsScene lds_stage(const DeviceScene& sc, const LdsLayout& lay, char* sme
   l.cand_cap = lay.cand_rows;
   l.overflow = lay.overflow ? lay.overflow + (blockIdx.x * block + tid) : nullptr;
   l.overflow_stride = lay.overflow_stride;
-  l.ops_offset = 32u * lay.n_nodes + kPrimHotBytes * lay.n_prims;
+  l.ops_offset = 32u * lay.n_nodes + 16u * PRIM_QUADS * lay.n_prims;
   return l;
 }
 
@@ -563,31 +572,43 @@ RT_DEV void wave_lds_sync() {
 // traversal stack), and the owner takes the accepted candidate with the lowest number.
 // The candidates, their order and therefore the result are exactly the lone
 // lane's; only who evaluates them changes.  Must be called by all 64 lanes.
-RT_DEV V3 wave_rand_in_unit_sphere(bool need, const DrawKey& key, lds_u32* xch, uint32_t row,
-                                   Stats& st) {
+//
+// `need_u` (never together with `need`): the lane wants the uniform of Dielectric::scatter's
+// reflect-or-refract choice instead (dielectric.rs:27: block DRAW_FRESNEL, seq 0).  It rides
+// along in the first trip as one more owner whose candidate number 0 is always taken, so a wave
+// that holds a few glass hits does not run a whole generator block for them alone; `u_out`
+// receives the same value a lone draw gives.
+RT_DEV V3 wave_rand_in_unit_sphere(bool need, bool need_u, const DrawKey& key, lds_u32* xch, uint32_t row,
+                                   Stats& st, double& u_out) {
   const uint32_t lane = __lane_id();
-  unsigned long long pending = __ballot(need);
+  unsigned long long vpend = __ballot(need), upend = __ballot(need_u);
   uint32_t tried = 0;
   V3 v = v3(0.0, 0.0, 0.0);
-  while (pending != 0ull) {
+  while ((vpend | upend) != 0ull) {
     RT_LP(st, LP_REJECT);
-    const uint32_t n = (uint32_t)__popcll(pending);
+    const uint32_t nu = (uint32_t)__popcll(upend), n = nu + (uint32_t)__popcll(vpend);
     const uint32_t c_log = n == 1u ? 6u : (uint32_t)__clz((int)(n - 1u)) - 26u;
-    const bool mine = (pending >> lane) & 1ull;
+    const bool mine_v = (vpend >> lane) & 1ull, mine_u = (upend >> lane) & 1ull;
     if (c_log == 0u) {
       // more than half of the wave is looking: no helper to share, each lane tries its own next
       // candidate and nothing is exchanged
       double x, y, z;
-      sym3_42(draw_block(key.seed, key.pixel, key.sample, key.bounce, DRAW_SCATTER, tried), x, y, z);
-      const bool got = mine && tried < kMaxRejections &&
+      const u32x4 b = draw_block(key.seed, key.pixel, key.sample, key.bounce,
+                                 mine_u ? (uint32_t)DRAW_FRESNEL : (uint32_t)DRAW_SCATTER, mine_u ? 0u : tried);
+      sym3_42(b, x, y, z);
+      if (mine_u) u_out = u01_53(b.x, b.y);
+      const bool got = mine_v && tried < kMaxRejections &&
                        (x * x + y * y + z * z < 1.0 || tried == kMaxRejections - 1u);
       if (got) v = v3(x, y, z);
-      pending &= ~__ballot(got);
+      vpend &= ~__ballot(got);
+      upend = 0ull;
       tried += 1u;
       continue;
     }
-    const uint32_t rank = (uint32_t)__popcll(pending & ((1ull << lane) - 1ull));
-    if (mine) {
+    // owners in rank order: the uniform requests first (nu is the same for every lane)
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const uint32_t rank = mine_u ? (uint32_t)__popcll(upend & below) : nu + (uint32_t)__popcll(vpend & below);
+    if (mine_v || mine_u) {
       xch[rank] = key.pixel;
       xch[row + rank] = key.sample;
     }
@@ -595,25 +616,41 @@ RT_DEV V3 wave_rand_in_unit_sphere(bool need, const DrawKey& key, lds_u32* xch, 
     const uint32_t q = lane >> c_log, sub = lane & ((1u << c_log) - 1u);
     const bool active = q < n;
     const uint32_t qq = active ? q : 0u;
-    const uint32_t seq = tried + sub;
+    const bool for_u = qq < nu;
+    const uint32_t seq = for_u ? sub : tried + sub;
     double x, y, z;
-    sym3_42(draw_block(key.seed, xch[qq], xch[row + qq], key.bounce, DRAW_SCATTER, seq), x, y, z);
+    const u32x4 b = draw_block(key.seed, xch[qq], xch[row + qq], key.bounce,
+                               for_u ? (uint32_t)DRAW_FRESNEL : (uint32_t)DRAW_SCATTER, seq);
+    sym3_42(b, x, y, z);
     // the lone loop gives up after kMaxRejections candidates and keeps the last one
-    const bool ok = active && seq < kMaxRejections &&
-                    (x * x + y * y + z * z < 1.0 || seq == kMaxRejections - 1u);
+    const bool ok = active && (for_u ? sub == 0u
+                                     : (seq < kMaxRejections &&
+                                        (x * x + y * y + z * z < 1.0 || seq == kMaxRejections - 1u)));
     const unsigned long long accepted = __ballot(ok);
     const uint32_t shift = rank << c_log;
     const unsigned long long group = c_log == 6u ? ~0ull : ((1ull << (1u << c_log)) - 1ull);
-    const unsigned long long m = mine ? ((accepted >> shift) & group) : 0ull;
+    const unsigned long long m = (mine_v || mine_u) ? ((accepted >> shift) & group) : 0ull;
     const bool got = m != 0ull;
     const int src = got ? (int)(shift + (uint32_t)__ffsll((long long)m) - 1u) : (int)lane;
-    const double fx = __shfl(x, src), fy = __shfl(y, src), fz = __shfl(z, src);
-    if (got) v = v3(fx, fy, fz);
-    pending &= ~__ballot(got);
+    // a uniform request gets the block's first two words back, untouched, in the place of x
+    const double px = for_u ? __longlong_as_double((long long)(((uint64_t)b.y << 32) | b.x)) : x;
+    const double fx = __shfl(px, src), fy = __shfl(y, src), fz = __shfl(z, src);
+    if (got && mine_v) v = v3(fx, fy, fz);
+    if (got && mine_u) {
+      const uint64_t w = (uint64_t)__double_as_longlong(fx);
+      u_out = u01_53((uint32_t)w, (uint32_t)(w >> 32));
+    }
+    vpend &= ~__ballot(got && mine_v);
+    upend = 0ull;
     tried += 1u << c_log;
     wave_lds_sync();
   }
   return v;
+}
+RT_DEV V3 wave_rand_in_unit_sphere(bool need, const DrawKey& key, lds_u32* xch, uint32_t row,
+                                   Stats& st) {
+  double unused = 0.0;
+  return wave_rand_in_unit_sphere(need, false, key, xch, row, st, unused);
 }
 
 // Leaf slot `slot` as the traversal needs it: the first 48 bytes from LDS when staged, and
@@ -711,7 +748,10 @@ RT_HD uint32_t stack_t_bits(float t, uint32_t bits) {
 // MEDIA: constant media are tested (else skipped); CHAINS: records tied to the reference's
 // box chain are checked against it; OVERFLOW: the hierarchy can need more stack entries than
 // LDS holds per lane, the rest live in the global overflow area.
-template <bool STATS, bool MEDIA, bool CHAINS, bool OVERFLOW>
+// SPHERES: every leaf slot is a plain sphere without wrappers (the hierarchy's workgroup copy
+// then holds 32 bytes per slot, centre and radius); `kind` of the result is left 0, the caller
+// reads the record of the slot it shades.
+template <bool STATS, bool MEDIA, bool CHAINS, bool OVERFLOW, bool SPHERES = false>
 RT_DEV Closest closest_hit(const DeviceScene& sc, const LdsScene& lds, V3 o, V3 d, double time,
                            double tmin, const DrawKey& key, Stats& st) {
   lds_u32* stack = lds.stack;
@@ -841,6 +881,24 @@ RT_DEV Closest closest_hit(const DeviceScene& sc, const LdsScene& lds, V3 o, V3 
     for (uint32_t k = 0; k < leaf_count; ++k) {
       RT_LP(st, LP_LEAFPRIM);
       uint32_t slot = leaf_first + k;
+      if (SPHERES) {
+        union {
+          f32x4 q[2];
+          double p[4];
+        } u;
+        if (slot < lds.n_prims) {
+          u.q[0] = lds.prims[2u * slot];
+          u.q[1] = lds.prims[2u * slot + 1u];
+        } else {
+          const f32x4* g = (const f32x4*)(sc.prims + slot);
+          u.q[0] = g[0];
+          u.q[1] = g[1];
+        }
+        stat<STATS>(st, RT_STAT_SPHERE_TESTS);
+        double t;
+        if (sphere_t<STATS>(v3(u.p[0], u.p[1], u.p[2]), u.p[3], o, d, dd, tmin, inf, t, st)) take(t, slot, 0u);
+        continue;
+      }
       const DPrim pr = load_prim<false>(sc, lds, slot);
       double t;
       bool hit;
