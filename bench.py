@@ -2,6 +2,7 @@
 """Headline benchmark: pixel-samples/s on book_cover at 1920x1080, 1024 spp.
 
   python bench.py --gpus 1 --steps 3 --warmup 1
+  python bench.py --config cornell|book2|cover1m      (the other named configurations, same JSON)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
       --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -42,6 +43,23 @@ from raytracer_amd.scene import HostScene  # noqa: E402
 
 SCENE = os.path.join(ROOT, "tests", "golden", "book_cover.rtscene")
 WIDTH, HEIGHT, SPP, SEED = 1920, 1080, 1024, 1
+# The named configurations: scene, frame, samples; `cpu` = the bounded sample the CPU restatement is
+# timed on (window or None for the whole frame, samples), sized for 5-30 s on 16 host threads;
+# `stats_spp` = samples of the instrumented pass the operation counts come from (scaled to spp);
+# `parity_spp` = samples of the crop compared with the CPU restatement.
+CONFIGS = {
+    "book_cover": dict(scene="book_cover", width=1920, height=1080, spp=1024, cpu=(None, 8), stats_spp=1024, parity_spp=1024,
+                       data="synthetic: book_cover.ron's random sphere pattern expanded by the seeded loader "
+                            "(scene seed 1, 488 spheres), frozen under tests/golden"),
+    "cornell": dict(scene="cornell", width=1024, height=1024, spp=4096, cpu=(None, 4), stats_spp=256, parity_spp=1024,
+                    data="cornell.ron (18 rectangles, two rotated and translated boxes), frozen under tests/golden"),
+    "book2": dict(scene="book2", width=1920, height=1080, spp=2048, cpu=(None, 2), stats_spp=128, parity_spp=512,
+                  data="synthetic: book2.ron expanded by the seeded loader (scene seed 1, 10 370 objects, "
+                       "Perlin tables, decoded earthmap texels), frozen under tests/golden"),
+    "cover1m": dict(scene=None, width=3840, height=2160, spp=1024, cpu=((1680, 945, 480, 270), 1), stats_spp=32, parity_spp=64,
+                    data="synthetic: book_cover.ron's pattern scaled to a 1000x1000 grid by the seeded generator "
+                         "(scene seed 1, 1 000 004 spheres), hierarchy built on the device"),
+}
 
 # Algorithmic cost per operation, in flops (add/sub/mul/div/sqrt/min/max/compare = 1,
 # no FMA credit), from the reference's source lines:
@@ -59,6 +77,20 @@ F_SHADE = {"shade_lambertian": 40, "shade_metal": 55, "shade_dielectric": 80, "s
 F_TEX = {"tex_checker": 15, "tex_image": 8, "tex_perlin": 900}
 PEAK_F64_TFLOPS = 78.6  # MI355X vector FP64 (spec)
 PEAK_F32_TFLOPS = 157.3  # MI355X vector FP32 (spec): the slab tests run in f32
+
+
+def kernel_source_sha():
+    """Hash of the device sources a profile belongs to: a committed counter file names the hash it
+    was measured on, and its numbers are quoted only while the sources still have it."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "raytracer_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            h.update(name.encode())
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def extend_flops(st):
@@ -85,11 +117,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--width", type=int, default=WIDTH)
-    ap.add_argument("--height", type=int, default=HEIGHT)
-    ap.add_argument("--spp", type=int, default=SPP)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="book_cover")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--spp", type=int, default=None)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline and parity legs")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    full_size = args.width is None and args.height is None and args.spp is None
+    args.width = args.width or cfg["width"]
+    args.height = args.height or cfg["height"]
+    args.spp = args.spp or cfg["spp"]
 
     import torch
     import torch.distributed as dist
@@ -108,8 +146,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
 
-    scene = HostScene.load_frozen(SCENE)
-    scene.set_image(args.width, args.height)
+    if cfg["scene"] is None:  # the 1 000 004-sphere scale-up of book_cover.ron
+        scene = HostScene.generate_cover(500, scene_seed=1, width=args.width, height=args.height, spp=args.spp,
+                                         max_depth=50)
+    else:
+        scene = HostScene.load_frozen(os.path.join(ROOT, "tests", "golden", cfg["scene"] + ".rtscene"))
+        scene.set_image(args.width, args.height)
     depth = scene.max_depth
     ctx = Context(device=local_rank)
     ctx.upload(scene)
@@ -117,10 +159,14 @@ def main():
 
     timing_totals = np.zeros(abi.RT_STAT_COUNT, dtype=np.float64)
 
+    render_s = [0.0]
+
     def render_fn(lo, hi, buf, timing=False):
         p = ctx.params(args.width, args.height, lo, hi, depth, seed=SEED)
+        r0 = time.perf_counter()
         st = ctx.render_into(p, buf.data_ptr(), timing=timing)
         if timing:
+            render_s[0] += time.perf_counter() - r0
             timing_totals[:] += st.astype(np.float64)
 
     def step(timing):
@@ -141,9 +187,17 @@ def main():
         step(True)
     fence()
     elapsed = time.perf_counter() - t0
+    per_rank = None
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        # what each rank spent inside the library (its share of the samples) and, the rest of its
+        # step, in the reduce and the waits around it: so that a scaling run explains itself
+        mine = torch.tensor([render_s[0], elapsed - render_s[0]], dtype=torch.float64, device=device)
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        per_rank = [[1e3 * float(g[0]) / max(args.steps, 1), 1e3 * float(g[1]) / max(args.steps, 1)]
+                    for g in gathered]
         elapsed = float(t.item())
 
     pixel_samples = float(args.width) * args.height * args.spp * args.steps
@@ -159,21 +213,27 @@ def main():
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f64",
-        "data": "synthetic: book_cover.ron's random sphere pattern expanded by the seeded loader "
-                "(scene seed 1, 488 spheres), frozen under tests/golden",
+        "data": cfg["data"],
         "config": {
-            "workload": f"book_cover {args.width}x{args.height}, {args.spp} spp, max_depth {depth}",
-            "scene": "tests/golden/book_cover.rtscene",
+            "workload": f"{args.config} {args.width}x{args.height}, {args.spp} spp, max_depth {depth}",
+            "scene": f"tests/golden/{cfg['scene']}.rtscene" if cfg["scene"] else "rt_host_generate_cover(500)",
             "width": args.width, "height": args.height, "spp": args.spp, "max_depth": depth,
             "sampling_seed": SEED,
             "parallelism": f"sample-range x{world} + one reduce(sum) to rank 0",
         },
     }
 
+    if per_rank is not None:
+        result["per_rank_ms_per_step"] = {"render": [r[0] for r in per_rank],
+                                          "reduce_and_wait": [r[1] for r in per_rank]}
+
     if world == 1 and rank == 0:
-        # operation counts of exactly the work of one step, from the instrumented kernels
-        p = ctx.params(args.width, args.height, 0, args.spp, depth, seed=SEED)
+        # operation counts of the work of one step, from the instrumented kernels (the headline
+        # configuration: exactly its samples; the longer ones: a stated number of samples, scaled)
+        stats_spp = min(args.spp, cfg["stats_spp"])
+        p = ctx.params(args.width, args.height, 0, stats_spp, depth, seed=SEED)
         _, st = ctx.render(p, dtype=np.float32, stats=True)
+        st = st.astype(np.float64) * (args.spp / stats_spp)
         ext_s = timing_totals[abi.STAT_NAMES.index("extend_ns")] * 1e-9
         ext_launches = timing_totals[abi.STAT_NAMES.index("extend_launches")]
         shade_s = timing_totals[abi.STAT_NAMES.index("shade_ns")] * 1e-9
@@ -204,41 +264,60 @@ def main():
             "rays_per_pixel_sample": rays / (args.width * args.height * args.spp),
             "box_tests_per_ray": float(st[abi.STAT_NAMES.index("box_tests")]) / rays,
             "sphere_tests_per_ray": float(st[abi.STAT_NAMES.index("sphere_tests")]) / rays,
+            "rect_tests_per_ray": float(st[abi.STAT_NAMES.index("rect_tests")]) / rays,
             "grays_per_s": rays * args.steps / elapsed / 1e9,
+            "counts_from": f"instrumented pass of {stats_spp} of the {args.spp} samples"
+                           + ("" if stats_spp == args.spp else ", scaled"),
         }
-        # HBM bytes per launch come from separate rocprofv3 counter passes over the same kernel and
-        # pass size (committed next to the kernel-trace summary); the counters cannot run in here
-        tpath = os.path.join(ROOT, "profiles", "r02_trace_kernel_hbm_traffic.json")
-        if fused and os.path.exists(tpath) and (args.width, args.height) == (WIDTH, HEIGHT) and args.spp >= 64:
+        # HBM bytes come from separate rocprofv3 counter passes over the same kernels
+        # (tools/profile_configs.sh; the counters cannot run in here).  The committed file names the
+        # hash of the device sources it was measured on: numbers of other sources are not quoted.
+        tpath = os.path.join(ROOT, "profiles", f"r03_{args.config}_roofline.json")
+        if full_size and os.path.exists(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
-            result["roofline"]["traffic"] = tj["hbm_bytes_per_launch"]
-            result["roofline"]["traffic_unit"] = ("bytes per launch (HBM, separate PMC passes over one pass of %d spp)"
-                                                  % tj.get("samples_per_pass", 64))
+            d = tj.get("derived", {})
+            if tj.get("kernel_source_sha") == kernel_source_sha() and "hbm_bytes_per_pixel_sample" in d:
+                # per launch of THIS run: bytes per pixel-sample of the profiled pass x this run's
+                # pixel-samples per launch
+                per_ps = d["hbm_bytes_per_pixel_sample"]
+                result["roofline"]["traffic"] = per_ps * args.width * args.height * args.spp * args.steps / max(ext_launches, 1)
+                result["roofline"]["traffic_unit"] = "HBM bytes per launch of this run"
+                result["roofline"]["traffic_per_pixel_sample"] = per_ps
+                result["roofline"]["traffic_per_ray"] = d.get("hbm_bytes_per_ray")
+                result["roofline"]["traffic_source"] = f"profiles/r03_{args.config}_roofline.json (" + tj.get("config", "") + ")"
+                for k in ("lanes_active", "valu_issue_share", "waves_per_simd", "l2_hit_rate", "hbm_gbps"):
+                    if k in d:
+                        result["roofline"][k] = d[k]
+            else:
+                result["roofline"]["traffic_source"] = (f"profiles/r03_{args.config}_roofline.json is of other device "
+                                                        "sources than this build: not quoted")
         if not args.no_cpu:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import pyoracle as po
             o = po.Oracle(scene.view_ptr)
             cores = po.hardware_threads()  # every host core this process may use
-            # bounded sample of the same workload: the whole frame at 8 spp (~5 s on 16 cores)
-            cpu_full_spp = 8
-            pf = po.make_params(args.width, args.height, 0, cpu_full_spp, depth, SEED)
+            # bounded sample of the same workload (see CONFIGS)
+            cpu_window, cpu_full_spp = cfg["cpu"]
+            pf = po.make_params(args.width, args.height, 0, cpu_full_spp, depth, SEED, window=cpu_window)
+            cpu_pixels = args.width * args.height if cpu_window is None else cpu_window[2] * cpu_window[3]
             c0 = time.perf_counter()
             o.render(pf, po.MODE_REFERENCE, threads=cores)
             cpu_s = time.perf_counter() - c0
             result["cpu_baseline"] = {
-                "value": args.width * args.height * cpu_full_spp / cpu_s,
+                "value": cpu_pixels * cpu_full_spp / cpu_s,
                 "unit": "pixel-samples/s",
                 "cores": cores,
                 "kind": "port",
-                "sample": f"the whole {args.width}x{args.height} frame at {cpu_full_spp} spp "
-                          f"({args.width * args.height * cpu_full_spp} pixel-samples), reference BVH "
-                          "topology, recursive ray_color, f64",
+                "sample": (f"the whole {args.width}x{args.height} frame" if cpu_window is None else
+                           f"the window {cpu_window} of the {args.width}x{args.height} frame")
+                          + f" at {cpu_full_spp} spp ({cpu_pixels * cpu_full_spp} pixel-samples, {cpu_s:.1f} s), "
+                          "reference BVH topology, recursive ray_color, f64",
             }
             # image comparison on a centred crop at the full spp
             cw, ch = 64, 36
             window = ((args.width - cw) // 2, (args.height - ch) // 2, cw, ch)
-            cpu_spp = args.spp
+            cpu_spp = min(args.spp, cfg["parity_spp"])
             pc = po.make_params(args.width, args.height, 0, cpu_spp, depth, SEED, window=window)
             cpu_a = o.render(pc, po.MODE_REFERENCE, threads=cores)
             pc2 = po.make_params(args.width, args.height, 0, cpu_spp, depth, SEED + 1, window=window)

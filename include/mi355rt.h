@@ -331,10 +331,12 @@ int rt_render_f64(rt_ctx* ctx, const rt_render_params* p, double* rgb_sum, uint6
 int rt_render_device(rt_ctx* ctx, const rt_render_params* p, float* d_rgb_sum, uint64_t* stats);
 
 /* No counterpart in the reference.  For callers that cannot allocate device memory while
- * they render (code under HIP graph capture, tight serving loops, harnesses that forbid
- * hipMalloc): the same sums as rt_render_device, with every intermediate buffer (path state,
+ * they render (tight serving loops, harnesses that forbid hipMalloc, code that sets up a HIP
+ * graph capture elsewhere and must not disturb the allocator): the same sums as rt_render_device, with every intermediate buffer (path state,
  * live-path queues, counters, the f64 sums) in a fixed RT_NOALLOC_SCRATCH_BYTES array that is
  * part of the library's code object, one copy per GPU.  The call allocates and frees nothing.
+ * It is NOT itself capturable into a HIP graph: like rt_render_device it synchronises its stream
+ * and reads back live-path counts between launches to size the next ones.
  * Limits: a window whose single-sample pass does not fit the array is refused with
  * RT_ERR_LIMIT (about 2^18 pixels at depth 50); no statistics or launch timing.  Every call on
  * a GPU shares that GPU's array, whichever context makes it: calls that overlap on one GPU

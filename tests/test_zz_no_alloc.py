@@ -16,7 +16,13 @@ def _pair(ctx, torch, w, h, window, s0, s1, depth, seed):
     a = torch.full((hh, ww, 3), -1.0, dtype=torch.float32, device="cuda:0")
     b = torch.full((hh, ww, 3), -2.0, dtype=torch.float32, device="cuda:0")
     ctx.render_into(ctx.params(w, h, s0, s1, depth, seed=seed, window=window), a.data_ptr())
+    torch.cuda.synchronize()
+    # the entry point must leave the device's free memory where it found it: an allocation of a
+    # megabyte or more (path buffers are hundreds) would show here
+    free_before, _ = torch.cuda.mem_get_info(0)
     ctx.render_into_noalloc(ctx.params(w, h, s0, s1, depth, seed=seed, window=window), b.data_ptr())
+    free_after, _ = torch.cuda.mem_get_info(0)
+    assert free_after == free_before, f"free device memory moved by {free_before - free_after} bytes"
     torch.cuda.synchronize()
     return a.cpu().numpy(), b.cpu().numpy()
 
