@@ -127,6 +127,83 @@ def image_gate(ctx, scene, name, width, height, spp, cw, ch, seeds=(1, 2, 3)):
     return ev
 
 
+def frame_statistic_gate(ctx, scene, width, height, dev_spp=64, dev_batches=16, cpu_spp=16, cpu_batches=16,
+                         tile=8, seeds=(3, 2)):
+    """A whole-frame statistic that can fail: the device under seed C against the oracle under
+    seed B, two independent estimates of the same image (src/main.rs:87-98), over EVERY pixel.
+
+    Both renders are made in batches of samples (disjoint sample ranges), so each side brings its
+    own variance estimate: for the frame mean and for the mean of every tile x tile block, per
+    channel, var = variance of the batch means / number of batches.  Checked:
+      frame   |mean_D - mean_O| <= 5 standard errors, per channel (book_cover at 1920x1080: a
+              relative bias of 2e-4 of the frame's radiance would show);
+      tiles   R = sum (D_T - O_T)^2 / sum (var_D_T + var_O_T) over all tiles and channels is 1 in
+              expectation when both sample the same image.  For N independent normal terms its
+              standard deviation is sqrt(2 / N); the three channels of a tile share their paths
+              and the variance estimates have 15 degrees of freedom each, which the oracle's own
+              two-seed runs put at about four times that (book_cover, N = 83 005: R = 1.002;
+              cornell 256x256, N = 3069, four seed pairs: 0.95 .. 1.06).  Bound: |R - 1| <=
+              12 sqrt(2 / N), at least 0.03: 0.06 on the 1920x1080 frame, where a disagreement
+              of a quarter sigma in every tile, or of 8 sigma in 0.1 % of them, fails;
+      outliers  share of tile-channels with |z| > 5 at most 1e-3, and with |z| > 7 at most
+              1 + 1e-5 N of them (a t variable with 30 degrees of freedom exceeds 5 with
+              probability 2e-5; heavy-tailed tiles, a light seen through two mirrors, raise that):
+              a locally wrong object shows here.
+    Radiance is compared unclamped (per-sample means), which is what both sides sum.
+    """
+    seed_c, seed_b = seeds
+    depth = scene.max_depth
+    oracle = po.Oracle(scene.view_ptr)
+    assert width % tile == 0 and height % tile == 0 and dev_spp % dev_batches == 0 and cpu_spp % cpu_batches == 0
+
+    def tiles(img, n):  # per-sample mean radiance of every tile, [H/tile, W/tile, 3]
+        t = img.reshape(height // tile, tile, width // tile, tile, 3).sum(axis=(1, 3))
+        return t / (n * tile * tile)
+
+    t0 = time.perf_counter()
+    db = dev_spp // dev_batches
+    dev = np.stack([tiles(ctx.render(ctx.params(width, height, k * db, (k + 1) * db, depth, seed=seed_c),
+                                     dtype=np.float64), db) for k in range(dev_batches)])
+    gpu_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    cb = cpu_spp // cpu_batches
+    cpu = np.stack([tiles(oracle.render(po.make_params(width, height, k * cb, (k + 1) * cb, depth, seed_b),
+                                        po.MODE_REFERENCE, threads=threads()), cb) for k in range(cpu_batches)])
+    cpu_s = time.perf_counter() - t0
+    d_mean, o_mean = dev.mean(axis=0), cpu.mean(axis=0)
+    d_var = dev.var(axis=0, ddof=1) / dev_batches
+    o_var = cpu.var(axis=0, ddof=1) / cpu_batches
+    diff = d_mean - o_mean
+    var = d_var + o_var
+    live = var > 0.0  # (a tile both sides see as constant, e.g. all black, must simply agree)
+    assert np.all(np.abs(diff[~live]) <= 1e-12), float(np.abs(diff[~live]).max())
+    z = np.zeros_like(diff)
+    z[live] = diff[live] / np.sqrt(var[live])
+    ratio = float((diff[live] ** 2).sum() / var[live].sum())
+    # frame means and their standard errors from the batches' frame means
+    d_frame, o_frame = dev.mean(axis=(1, 2)), cpu.mean(axis=(1, 2))  # [batches, 3]
+    f_diff = d_frame.mean(axis=0) - o_frame.mean(axis=0)
+    f_se = np.sqrt(d_frame.var(axis=0, ddof=1) / dev_batches + o_frame.var(axis=0, ddof=1) / cpu_batches)
+    f_z = f_diff / f_se
+    n_live = int(live.sum())
+    ev = {
+        "width": width, "height": height, "max_depth": depth, "tile": tile,
+        "device": {"seed": seed_c, "spp": dev_spp, "batches": dev_batches, "seconds": gpu_s},
+        "oracle": {"seed": seed_b, "spp": cpu_spp, "batches": cpu_batches, "seconds": cpu_s, "threads": threads()},
+        "frame_mean_device": d_frame.mean(axis=0).tolist(), "frame_mean_oracle": o_frame.mean(axis=0).tolist(),
+        "frame_z": f_z.tolist(), "frame_rel_diff": (f_diff / o_frame.mean(axis=0)).tolist(),
+        "tile_channels": n_live, "tile_ratio": ratio, "tile_ratio_sd_expected": float(np.sqrt(2.0 / max(n_live, 1))),
+        "tile_z_max": float(np.abs(z).max()), "tile_z_over_5_share": float((np.abs(z) > 5.0).sum() / max(n_live, 1)),
+        "tile_z_over_7": int((np.abs(z) > 7.0).sum()),
+        "tile_ratio_bound": max(0.03, 12.0 * float(np.sqrt(2.0 / max(n_live, 1)))),
+    }
+    assert np.all(np.abs(f_z) <= 5.0), ev
+    assert abs(ratio - 1.0) <= ev["tile_ratio_bound"], ev
+    assert ev["tile_z_over_5_share"] <= 1e-3, ev
+    assert ev["tile_z_over_7"] <= 1 + 1e-5 * n_live, ev
+    return ev
+
+
 def cover_scene(half_extent, width, height):
     """The book_cover-style generator (ground + (2 half)^2 small spheres + 3 big ones)."""
     return HostScene.generate_cover(half_extent, scene_seed=1, width=width, height=height, spp=1024,

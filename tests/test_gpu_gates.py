@@ -34,6 +34,18 @@ def test_image_gate_at_4096_spp(gpu_ctx, name, cw, ch):
         assert ev["max_abs_mean_diff_same_seed"] <= 1e-12
 
 
+@pytest.mark.parametrize("name,w,h,dev_spp,cpu_spp", [("book_cover", 1920, 1080, 64, 16), ("cornell", 256, 256, 256, 64),
+                                                     ("book2", 480, 272, 64, 16)])
+def test_whole_frame_statistic(gpu_ctx, name, w, h, dev_spp, cpu_spp):
+    """Every pixel of the frame, device seed C against oracle seed B (gates.frame_statistic_gate);
+    cornell (a light of radiance 15 in a closed box: heavy-tailed samples) with four times the samples."""
+    scene = gates.load(name, w, h)
+    gpu_ctx.upload(scene)
+    ev = gates.frame_statistic_gate(gpu_ctx, scene, w, h, dev_spp=dev_spp, cpu_spp=cpu_spp)
+    print(name, ev)
+    assert ev["tile_channels"] > 0.5 * (w // 8) * (h // 8) * 3
+
+
 def test_million_sphere_cover_at_3840x2160(gpu_ctx):
     w, h = 3840, 2160
     scene = gates.cover_scene(500, w, h)
