@@ -579,7 +579,7 @@ uint32_t stack_need(const std::vector<rt_bvh_node>& out) {
   std::vector<uint32_t> need(out.size(), 0);
   for (size_t i = out.size(); i-- > 0;) {
     if (!(out[i].b & 0x80000000u)) continue;
-    uint32_t k = (out[i].b & 3u) + 1u, deepest = 0;
+    uint32_t k = (out[i].b & (kWide - 1u)) + 1u, deepest = 0;
     for (uint32_t c = 0; c < k; ++c) deepest = std::max(deepest, need[out[i].a + c]);
     need[i] = (k - 1u) + deepest;
   }
@@ -611,9 +611,9 @@ uint32_t collapse_wide(const std::vector<BinNode>& bin, std::vector<rt_bvh_node>
       continue;
     }
     // expand the interior child with the largest box until there are four
-    uint32_t kids[4] = {n.left, n.left + 1, 0, 0};
+    uint32_t kids[kWide] = {n.left, n.left + 1};
     uint32_t k = 2;
-    while (k < 4) {
+    while (k < kWide) {
       int pick = -1;
       double area = -1.0;
       for (uint32_t i = 0; i < k; ++i)

@@ -82,6 +82,14 @@ struct DImage {  // 16 bytes
   uint64_t offset;
 };
 
+// Children per interior record of the wide hierarchy: 4 as shipped; a build with -DRT_WIDE=8
+// (every file of the library) walks eight-wide records instead, the host's builder only.
+#ifndef RT_WIDE
+#define RT_WIDE 4
+#endif
+const uint32_t kWide = RT_WIDE;
+const uint32_t kWideBits = RT_WIDE == 8 ? 3u : 2u;
+static_assert(RT_WIDE == 4 || RT_WIDE == 8, "RT_WIDE must be 4 or 8");
 const uint32_t kMaxBvhDepth = 32;      // levels of the binary tree the wide one is collapsed from
 const uint32_t kMaxLeafItems = 8;     // upper bound; the builder's default is lower
 const uint32_t kNoPrim = 0xFFFFFFFFu;

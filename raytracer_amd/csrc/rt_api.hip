@@ -659,11 +659,15 @@ RT_DEV void wave_flush(const uint32_t* stage, uint32_t n, uint32_t* g_counter, u
 // camera rays of every path of the pass; a variant of its own so that the other bounces do not
 // carry the camera block in scalar registers: that pressure showed as scalar spills all
 // through the per-trip code).
-enum { kTraceBounce = 0, kTraceTail = 1, kTraceFirst = 2 };
+// kTraceTailTextured: the tail of a scene with procedural or image textures.  Those hits are
+// deferred to a kernel of their own in the other modes (a Perlin walk needs twice the registers
+// of everything else); the tail's few paths are shaded in place under a register budget of their
+// own (two waves per SIMD), so that the last dozens of bounces are one launch here as well.
+enum { kTraceBounce = 0, kTraceTail = 1, kTraceFirst = 2, kTraceTailTextured = 3 };
 // Waves per SIMD the register allocation is made for.  The instrumented (STATS) variants carry
 // two dozen counters per lane and are not timed: they get registers enough not to spill at all.
-constexpr int trace_waves_per_simd(int block, bool stats, bool media) {
-  return stats ? (block >= 512 ? 2 : 1) : media ? RT_TRACE_MEDIA_WAVES : 4;
+constexpr int trace_waves_per_simd(int block, bool stats, bool media, int mode = kTraceBounce) {
+  return stats ? (block >= 512 ? 2 : 1) : mode == kTraceTailTextured ? 2 : media ? RT_TRACE_MEDIA_WAVES : 4;
 }
 // SPHERES: every leaf slot of the scene is a plain sphere without wrappers and nothing is deferred
 // (the reference's book_cover.ron and its scale-ups): the leaf test, the hit record and the
@@ -672,11 +676,13 @@ constexpr int trace_waves_per_simd(int block, bool stats, bool media) {
 // its attenuation, written by the first bounce: the variants without media read them back after
 // the walk instead of deriving them from the path index again on every bounce.
 template <int BLOCK, bool STATS, bool MEDIA, bool OVERFLOW, int MODE, bool SPHERES = false>
-__global__ void __launch_bounds__(BLOCK, trace_waves_per_simd(BLOCK, STATS, MEDIA))
+__global__ void __launch_bounds__(BLOCK, trace_waves_per_simd(BLOCK, STATS, MEDIA, MODE))
 trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_t first_bounce_arg,
              uint32_t max_depth, unsigned long long* g_stats) {
   static_assert(!(MEDIA && SPHERES), "the sphere-only variant carries no media");
-  constexpr bool TAIL = MODE == kTraceTail, FIRST = MODE == kTraceFirst;
+  constexpr bool TEXTURED = MODE == kTraceTailTextured;
+  static_assert(!(TEXTURED && SPHERES), "the sphere-only variant defers nothing");
+  constexpr bool TAIL = MODE == kTraceTail || TEXTURED, FIRST = MODE == kTraceFirst;
   constexpr bool KEY_FROM_PATH = FIRST || MEDIA;  // else from the path's attenuation record
   const uint32_t first_bounce = FIRST ? 0u : first_bounce_arg;
   extern __shared__ __align__(16) char smem[];
@@ -807,8 +813,8 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
             const bool whole = (h.kind & kMaterialElsewhereBit) != 0u;
             pr = whole ? load_prim<true>(sc, lds, h.item) : load_prim<false>(sc, lds, h.item);
           }
-          so = shade_begin<STATS, true, SPHERES, true>(sc, (h.kind >> 8) & 7u, pr, material_of(pr), o, d, time, h.t,
-                                                       key, st);
+          so = shade_begin<STATS, !TEXTURED, SPHERES, true>(sc, (h.kind >> 8) & 7u, pr, material_of(pr), o, d, time,
+                                                            h.t, key, st);
           if (so.emits) {
             add = vmul(beta, so.emitted);
             adds = true;
@@ -949,7 +955,7 @@ device_records_kernel(rt_bvh_node* records, uint32_t n) {
   if (i < n) {
     records[i].a = make_entry(records[i].a, records[i].b);
     records[i].b = 0;
-  } else if (i < n + 3u) {
+  } else if (i < n + kWide - 1u) {
     rt_bvh_node pad;
     for (int a = 0; a < 3; ++a) {
       pad.lo[a] = __int_as_float(0x7F800000);
@@ -1063,6 +1069,7 @@ struct rt_ctx {
   uint32_t pb_queues = 0;  // bin queues allocated in pb.bins
   bool solid = true;       // every texture is a SolidColor
   bool general = false;    // the scene needs the general trace kernel
+  bool textured_tail = true;  // scenes with procedural or image textures run the tail launch too (MI355RT_TEXTURED_TAIL=0: no)
   bool spheres = false;    // every leaf slot is a plain sphere without wrappers: the sphere-only trace kernel
   uint32_t counters_depth = 0;
   DeviceArray<double> accum;
@@ -1278,7 +1285,7 @@ LdsLayout plan_lds(const FlatScene& f, uint32_t block, uint32_t budget, uint32_t
   budget = std::max(budget, used + 4096u);  // leave room for a few records
   uint32_t room = budget - used;
   // (+3: the never-hit records that end the device copy, so the last group stays in LDS)
-  l.n_nodes = std::min<uint32_t>((uint32_t)f.nodes.size() + 3u, room / 32u);
+  l.n_nodes = std::min<uint32_t>((uint32_t)f.nodes.size() + kWide - 1u, room / 32u);
   room -= l.n_nodes * 32u;
   l.n_prims = std::min<uint32_t>((uint32_t)f.prims.size(), room / slot_bytes);
   l.bytes = used + l.n_nodes * 32u + l.n_prims * slot_bytes;
@@ -1287,7 +1294,14 @@ LdsLayout plan_lds(const FlatScene& f, uint32_t block, uint32_t budget, uint32_t
 
 // A run-time trace mode as a compile-time one.
 template <typename F>
+auto with_mode3(int mode, F&& f) {  // (the modes of a scene without textures)
+  if (mode == kTraceTail) return f(std::integral_constant<int, kTraceTail>{});
+  if (mode == kTraceFirst) return f(std::integral_constant<int, kTraceFirst>{});
+  return f(std::integral_constant<int, kTraceBounce>{});
+}
+template <typename F>
 auto with_mode(int mode, F&& f) {
+  if (mode == kTraceTailTextured) return f(std::integral_constant<int, kTraceTailTextured>{});
   if (mode == kTraceTail) return f(std::integral_constant<int, kTraceTail>{});
   if (mode == kTraceFirst) return f(std::integral_constant<int, kTraceFirst>{});
   return f(std::integral_constant<int, kTraceBounce>{});
@@ -1304,7 +1318,7 @@ void launch_trace_spheres(rt_ctx* ctx, bool stats, bool tail, uint32_t grid, con
   const LdsLayout& l = ctx->lds_trace;
   with_bool(stats, [&](auto S) {
     return with_bool(l.overflow != nullptr, [&](auto O) {
-      return with_mode(tail ? kTraceTail : b == 0 ? kTraceFirst : kTraceBounce, [&](auto T) {
+      return with_mode3(tail ? kTraceTail : b == 0 ? kTraceFirst : kTraceBounce, [&](auto T) {
         trace_kernel<512, decltype(S)::value, false, decltype(O)::value, decltype(T)::value, true>
             <<<grid, 512, l.bytes, ctx->stream>>>(ctx->ds, l, pb, ps, b, max_depth, gs);
         return 0;
@@ -1320,7 +1334,8 @@ void launch_trace_block(rt_ctx* ctx, bool stats, bool media, bool tail, uint32_t
   with_bool(stats, [&](auto S) {
     return with_bool(media, [&](auto M) {
       return with_bool(l.overflow != nullptr, [&](auto O) {
-        return with_mode(tail ? kTraceTail : b == 0 ? kTraceFirst : kTraceBounce, [&](auto T) {
+        return with_mode(tail ? (ctx->solid ? kTraceTail : kTraceTailTextured) : b == 0 ? kTraceFirst : kTraceBounce,
+                         [&](auto T) {
           trace_kernel<BLOCK, decltype(S)::value, decltype(M)::value, decltype(O)::value,
                        decltype(T)::value>
               <<<grid, BLOCK, l.bytes, ctx->stream>>>(ctx->ds, l, pb, ps, b, max_depth, gs);
@@ -1354,7 +1369,7 @@ template <int BLOCK>
 hipError_t allow_trace_lds(int bytes) {
   const hipFuncAttribute attr = hipFuncAttributeMaxDynamicSharedMemorySize;
   hipError_t e = hipSuccess;
-  for (int v = 0; v < 24 && e == hipSuccess; ++v)
+  for (int v = 0; v < 32 && e == hipSuccess; ++v)
     e = with_bool(v & 1, [&](auto S) {
       return with_bool(v & 2, [&](auto M) {
         return with_bool(v & 4, [&](auto O) {
@@ -1375,7 +1390,7 @@ hipError_t allow_trace_spheres_lds(int bytes) {
   for (int v = 0; v < 12 && e == hipSuccess; ++v)
     e = with_bool(v & 1, [&](auto S) {
       return with_bool(v & 2, [&](auto O) {
-        return with_mode(v >> 2, [&](auto T) {
+        return with_mode3(v >> 2, [&](auto T) {
           return hipFuncSetAttribute(
               (const void*)trace_kernel<512, decltype(S)::value, false, decltype(O)::value, decltype(T)::value, true>,
               attr, bytes);
@@ -1571,7 +1586,7 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats, d
         if (live == 0) break;
         grid = std::max(1u, std::min(blocks_for(live), max_grid));
         tgrid = std::max(1u, trace_blocks_for(live));
-        if (fused && solid && live <= ctx->tail_paths) {
+        if (fused && (solid || ctx->textured_tail) && live <= ctx->tail_paths) {
           // few paths left: all remaining bounces in one launch
           if (want_timing) RT_HIP(ctx, stamp());
           launch_trace(ctx, want_stats, general, true, tgrid, pb, ps, b + 1, p->max_depth, gs);
@@ -1774,6 +1789,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene* scene) {
   // million spheres takes longer than rendering them.  MI355RT_DEVICE_BUILD=0 / 1: never / always.
   bool device_build = scene->n_prims >= (1u << 17);
   if (const char* e = getenv("MI355RT_DEVICE_BUILD")) device_build = atoi(e) != 0;
+  if (kWide != 4u) device_build = false;  // (the device's builder makes four-wide records)
   // Either device step may fail (out of memory, most likely); flatten_scene then does that step on
   // the host.  The runtime's error state is cleared here, or the next hipGetLastError() of the
   // upload would report the failure the fallback has just dealt with.
@@ -1831,12 +1847,12 @@ static int upload_flat(rt_ctx* ctx) {
     // never-hit records at the end so that a visit may always read four children
     ctx->nodes.release();
     const size_t n_rec = f.nodes.size();
-    RT_HIP(ctx, hipMalloc((void**)&ctx->nodes.p, (n_rec + 3) * sizeof(rt_bvh_node)));
-    ctx->nodes.n = 2 * (n_rec + 3);
+    RT_HIP(ctx, hipMalloc((void**)&ctx->nodes.p, (n_rec + kWide - 1u) * sizeof(rt_bvh_node)));
+    ctx->nodes.n = 2 * (n_rec + kWide - 1u);
     if (n_rec)
       RT_HIP(ctx, hipMemcpyAsync(ctx->nodes.p, f.nodes.data(), n_rec * sizeof(rt_bvh_node), hipMemcpyHostToDevice,
                                  ctx->stream));
-    device_records_kernel<<<blocks_for(n_rec + 3), kBlock, 0, ctx->stream>>>((rt_bvh_node*)ctx->nodes.p,
+    device_records_kernel<<<blocks_for(n_rec + kWide - 1u), kBlock, 0, ctx->stream>>>((rt_bvh_node*)ctx->nodes.p,
                                                                             (uint32_t)n_rec);
     RT_HIP(ctx, hipGetLastError());
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1888,6 +1904,7 @@ static int upload_flat(rt_ctx* ctx) {
     uint32_t stack_cap = 33u;
     if (const char* e = getenv("MI355RT_STACK_CAP")) stack_cap = (uint32_t)strtoul(e, nullptr, 10);
     if (const char* e = getenv("MI355RT_TAIL_PATHS")) ctx->tail_paths = (uint32_t)strtoul(e, nullptr, 10);
+    if (const char* e = getenv("MI355RT_TEXTURED_TAIL")) ctx->textured_tail = atoi(e) != 0;
     ctx->blocks_per_cu = 16u;
     if (const char* e = getenv("MI355RT_BLOCKS_PER_CU"))
       ctx->blocks_per_cu = std::max(1u, (uint32_t)strtoul(e, nullptr, 10));

@@ -725,11 +725,11 @@ RT_DEV bool reference_chain_passes(const DeviceScene& sc, uint32_t chain, V3 o, 
 const uint32_t kNoEntry = 0xFFFFFFFFu;
 
 RT_HD uint32_t make_entry(uint32_t a, uint32_t b) {
-  return (b & 0x80000000u) ? (((a << 2) | (b & 3u)) << 1) : ((((a << 3) | (b - 1u)) << 1) | 1u);
+  return (b & 0x80000000u) ? (((a << kWideBits) | (b & (kWide - 1u))) << 1) : ((((a << 3) | (b - 1u)) << 1) | 1u);
 }
 // Bits needed for every entry code of a hierarchy with this many records and items.
 RT_HD uint32_t entry_code_bits(uint32_t n_nodes, uint32_t n_items) {
-  uint32_t hi = (n_nodes << 3) > (n_items << 4) ? (n_nodes << 3) : (n_items << 4);
+  uint32_t hi = (n_nodes << (kWideBits + 1u)) > (n_items << 4) ? (n_nodes << (kWideBits + 1u)) : (n_items << 4);
   uint32_t bits = 1;
   while (bits < 31 && (hi >> bits) != 0) ++bits;
   return bits;
@@ -827,52 +827,55 @@ RT_DEV Closest closest_hit(const DeviceScene& sc, const LdsScene& lds, V3 o, V3 
         break;
       }
       RT_LP(st, LP_NODE);
-      const uint32_t first = cur >> 3, n = ((cur >> 1) & 3u) + 1u;
-      const bool in_lds = first + 4u <= lds.n_nodes;
-      f32x4 r[8];
-      if (in_lds) {
-#pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) r[k] = lds.nodes[2 * first + k];
-      } else {
-#pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) r[k] = gnodes[2 * first + k];
-      }
+      const uint32_t first = cur >> (kWideBits + 1u), n = ((cur >> 1) & (kWide - 1u)) + 1u;
+      const bool in_lds = first + kWide <= lds.n_nodes;
       if (STATS) {
         st.v[RT_STAT_BOX_TESTS] += n;
         st.v[RT_STAT_NODE_VISITS]++;
       }
-      uint32_t w[4];
+      uint32_t w[kWide];
 #pragma unroll
-      for (uint32_t k = 0; k < 4; ++k) {
-        const f32x4 n0 = r[2 * k], n1 = r[2 * k + 1];
-        // three packed FMAs: (ax ay) (az bx) (by bz)
-        const f32x2 pa = __builtin_elementwise_fma(f32x2{n0.x, n0.y}, mul_a, add_a);
-        const f32x2 pb = __builtin_elementwise_fma(f32x2{n0.z, n0.w}, mul_b, add_b);
-        const f32x2 pc = __builtin_elementwise_fma(f32x2{n1.x, n1.y}, mul_c, add_c);
-        const float ax = pa.x, ay = pa.y, az = pb.x, bx = pb.y, by = pc.x, bz = pc.y;
-        float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin32));
-        float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best32w));
-        const uint32_t word = ((__float_as_uint(t0) >> (ebits - 1u)) << ebits) | __float_as_uint(n1.z);
-        w[k] = (k < n && t0 <= t1) ? word : kNoEntry;
+      for (uint32_t half = 0; half < kWide / 4u; ++half) {  // four children at a time (their records: 32 registers)
+        f32x4 r[8];
+        if (in_lds) {
+#pragma unroll
+          for (uint32_t k = 0; k < 8; ++k) r[k] = lds.nodes[2 * first + 8 * half + k];
+        } else {
+#pragma unroll
+          for (uint32_t k = 0; k < 8; ++k) r[k] = gnodes[2 * first + 8 * half + k];
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+          const f32x4 n0 = r[2 * k], n1 = r[2 * k + 1];
+          // three packed FMAs: (ax ay) (az bx) (by bz)
+          const f32x2 pa = __builtin_elementwise_fma(f32x2{n0.x, n0.y}, mul_a, add_a);
+          const f32x2 pb = __builtin_elementwise_fma(f32x2{n0.z, n0.w}, mul_b, add_b);
+          const f32x2 pc = __builtin_elementwise_fma(f32x2{n1.x, n1.y}, mul_c, add_c);
+          const float ax = pa.x, ay = pa.y, az = pb.x, bx = pb.y, by = pc.x, bz = pc.y;
+          float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin32));
+          float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), best32w));
+          const uint32_t word = ((__float_as_uint(t0) >> (ebits - 1u)) << ebits) | __float_as_uint(n1.z);
+          w[4 * half + k] = (4 * half + k < n && t0 <= t1) ? word : kNoEntry;
+        }
       }
-      // sort ascending (five compare-exchanges)
-      {
-        uint32_t a0 = min(w[0], w[1]), a1 = max(w[0], w[1]);
-        uint32_t a2 = min(w[2], w[3]), a3 = max(w[2], w[3]);
-        uint32_t b0 = min(a0, a2), b2 = max(a0, a2);
-        uint32_t b1 = min(a1, a3), b3 = max(a1, a3);
-        w[0] = b0;
-        w[1] = min(b1, b2);
-        w[2] = max(b1, b2);
-        w[3] = b3;
+      // sort ascending
+      auto cx = [&](uint32_t i, uint32_t j) {
+        const uint32_t lo = min(w[i], w[j]), hi = max(w[i], w[j]);
+        w[i] = lo;
+        w[j] = hi;
+      };
+      if (kWide == 4) {  // five compare-exchanges
+        cx(0, 1); cx(2, 3); cx(0, 2); cx(1, 3); cx(1, 2);
+      } else {  // nineteen (the optimal network for eight inputs)
+        cx(0, 1); cx(2, 3); cx(4, 5); cx(6, 7); cx(0, 2); cx(1, 3); cx(4, 6); cx(5, 7); cx(1, 2); cx(5, 6);
+        cx(0, 4); cx(3, 7); cx(1, 5); cx(2, 6); cx(1, 4); cx(3, 6); cx(2, 4); cx(3, 5); cx(3, 4);
       }
       // stack the far hits, farthest first; a miss is overwritten by the next store
-      put(sp, w[3]);
-      sp += w[3] != kNoEntry ? 1u : 0u;
-      put(sp, w[2]);
-      sp += w[2] != kNoEntry ? 1u : 0u;
-      put(sp, w[1]);
-      sp += w[1] != kNoEntry ? 1u : 0u;
+#pragma unroll
+      for (uint32_t k = kWide - 1u; k >= 1u; --k) {
+        put(sp, w[k]);
+        sp += w[k] != kNoEntry ? 1u : 0u;
+      }
       cur = w[0] != kNoEntry ? (w[0] & emask) : pop();
     }
     if (leaf == kNoEntry) break;

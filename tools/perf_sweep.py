@@ -18,8 +18,11 @@ name, spp, w, h = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[
 sweeps = [a.split("=") for a in sys.argv[5:]]
 keys = [k for k, _ in sweeps]
 values = [v.split(",") for _, v in sweeps]
-scene = HostScene.load_frozen(os.path.join(ROOT, "tests", "golden", name + ".rtscene"))
-scene.set_image(w, h)
+if name == "cover1m":  # the 1,000,004-sphere scale-up of book_cover.ron
+    scene = HostScene.generate_cover(500, scene_seed=1, width=w, height=h, spp=spp, max_depth=50)
+else:
+    scene = HostScene.load_frozen(os.path.join(ROOT, "tests", "golden", name + ".rtscene"))
+    scene.set_image(w, h)
 depth = int(os.environ.get('SWEEP_DEPTH', scene.max_depth))
 ref = None
 for combo in itertools.product(*values) if values else [()]:
