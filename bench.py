@@ -51,12 +51,15 @@ CONFIGS = {
     "book_cover": dict(scene="book_cover", width=1920, height=1080, spp=1024, cpu=(None, 8), stats_spp=1024, parity_spp=1024,
                        data="synthetic: book_cover.ron's random sphere pattern expanded by the seeded loader "
                             "(scene seed 1, 488 spheres), frozen under tests/golden"),
+    "material_demo": dict(scene="material_demo", width=400, height=225, spp=64, cpu=(None, 64), stats_spp=64,
+                          parity_spp=64, data="material_demo.ron (4 spheres: the reference's own CPU-runnable case), "
+                                              "frozen under tests/golden"),
     "cornell": dict(scene="cornell", width=1024, height=1024, spp=4096, cpu=(None, 4), stats_spp=256, parity_spp=1024,
                     data="cornell.ron (18 rectangles, two rotated and translated boxes), frozen under tests/golden"),
     "book2": dict(scene="book2", width=1920, height=1080, spp=2048, cpu=(None, 2), stats_spp=128, parity_spp=512,
                   data="synthetic: book2.ron expanded by the seeded loader (scene seed 1, 10 370 objects, "
                        "Perlin tables, decoded earthmap texels), frozen under tests/golden"),
-    "cover1m": dict(scene=None, width=3840, height=2160, spp=1024, cpu=((1680, 945, 480, 270), 1), stats_spp=32, parity_spp=64,
+    "cover1m": dict(scene=None, width=3840, height=2160, spp=1024, cpu=((1800, 1012, 240, 135), 1), stats_spp=32, parity_spp=16, parity_crop=(32, 18),
                     data="synthetic: book_cover.ron's pattern scaled to a 1000x1000 grid by the seeded generator "
                          "(scene seed 1, 1 000 004 spheres), hierarchy built on the device"),
 }
@@ -110,6 +113,11 @@ def shade_flops(st):
     for k, f in list(F_SHADE.items()) + list(F_TEX.items()):
         total += g(k) * f
     return total
+
+
+def note(msg):
+    """Progress on stderr: a long configuration must not look hung to whoever runs it."""
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
 def main():
@@ -179,6 +187,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    note(f"{args.config}: scene uploaded, {args.warmup} warm-up + {args.steps} timed steps")
     for _ in range(args.warmup):
         step(False)
     fence()
@@ -230,6 +239,7 @@ def main():
     if world == 1 and rank == 0:
         # operation counts of the work of one step, from the instrumented kernels (the headline
         # configuration: exactly its samples; the longer ones: a stated number of samples, scaled)
+        note(f"timed steps done: {1e3 * elapsed / max(args.steps, 1):.1f} ms per step; instrumented pass")
         stats_spp = min(args.spp, cfg["stats_spp"])
         p = ctx.params(args.width, args.height, 0, stats_spp, depth, seed=SEED)
         _, st = ctx.render(p, dtype=np.float32, stats=True)
@@ -298,6 +308,7 @@ def main():
             o = po.Oracle(scene.view_ptr)
             cores = po.hardware_threads()  # every host core this process may use
             # bounded sample of the same workload (see CONFIGS)
+            note("CPU restatement: bounded sample")
             cpu_window, cpu_full_spp = cfg["cpu"]
             pf = po.make_params(args.width, args.height, 0, cpu_full_spp, depth, SEED, window=cpu_window)
             cpu_pixels = args.width * args.height if cpu_window is None else cpu_window[2] * cpu_window[3]
@@ -315,8 +326,9 @@ def main():
                           "reference BVH topology, recursive ray_color, f64",
             }
             # image comparison on a centred crop at the full spp
-            cw, ch = 64, 36
+            cw, ch = cfg.get("parity_crop", (64, 36))
             window = ((args.width - cw) // 2, (args.height - ch) // 2, cw, ch)
+            note(f"CPU restatement: {cpu_s:.1f} s; parity crop, two seeds")
             cpu_spp = min(args.spp, cfg["parity_spp"])
             pc = po.make_params(args.width, args.height, 0, cpu_spp, depth, SEED, window=window)
             cpu_a = o.render(pc, po.MODE_REFERENCE, threads=cores)

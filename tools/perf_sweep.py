@@ -27,8 +27,11 @@ depth = int(os.environ.get('SWEEP_DEPTH', scene.max_depth))
 ref = None
 for combo in itertools.product(*values) if values else [()]:
     flags = 0
+    timing = True
     for k, v in zip(keys, combo):
-        if k == "FLAGS":  # render flags (4 = force the binned extend/shade pipeline), not an env var
+        if k == "TIMING":  # 0: no events around the launches (what they cost shows in the wall time)
+            timing = v != "0"
+        elif k == "FLAGS":  # render flags (4 = force the binned extend/shade pipeline), not an env var
             flags = int(v)
         elif v == "-":
             os.environ.pop(k, None)
@@ -40,7 +43,7 @@ for combo in itertools.product(*values) if values else [()]:
     for rep in range(3):
         p = ctx.params(w, h, 0, spp, depth, seed=1, flags=flags)
         t0 = time.perf_counter()
-        img, st = ctx.render(p, dtype=np.float32, timing=True)
+        img, st = ctx.render(p, dtype=np.float32, timing=True) if timing else (ctx.render(p, dtype=np.float32), np.zeros(24))
         best = min(best, time.perf_counter() - t0)
     chk = float(img.astype(np.float64).sum())
     if ref is None:

@@ -13,7 +13,7 @@ def short(name):
               "to_float_kernel"):
         if k in name:
             tail = name[name.index(k):].split("(")[0]
-            return tail[:40]
+            return tail[:56].rstrip(">").rstrip()
     return name.split("(")[0][:60]
 
 
@@ -22,13 +22,13 @@ def main(root):
     if trace:
         db = sqlite3.connect(trace[0])
         print("== kernel trace (rocprofv3 --kernel-trace --stats) ==")
-        print(f"{'kernel':42s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>10s} {'pct':>6s} {'vgpr':>5s} {'sgpr':>5s} {'lds':>6s}")
+        print(f"{'kernel':58s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>10s} {'pct':>6s} {'vgpr':>5s} {'sgpr':>5s} {'lds':>6s}")
         rows = db.execute("select name, count(*), sum(duration), avg(duration), max(vgpr_count), "
                           "max(sgpr_count), max(lds_size) from kernels group by name "
                           "order by sum(duration) desc").fetchall()
         total = sum(r[2] for r in rows) or 1
         for n, c, tot, avg, vg, sg, lds in rows:
-            print(f"{short(n):42s} {c:7d} {tot / 1e6:10.3f} {avg / 1e3:10.2f} {100 * tot / total:6.1f} {vg:5d} {sg:5d} {lds:6d}")
+            print(f"{short(n):58s} {c:7d} {tot / 1e6:10.3f} {avg / 1e3:10.2f} {100 * tot / total:6.1f} {vg:5d} {sg:5d} {lds:6d}")
     for path in sorted(glob.glob(os.path.join(root, "pmc_*", "*.db"))):
         db = sqlite3.connect(path)
         print(f"\n== counters: {os.path.basename(os.path.dirname(path))} ==")
@@ -41,7 +41,7 @@ def main(root):
             print("  (could not join:", e, cols, ")")
             continue
         for n, cname, val, cnt in rows:
-            print(f"  {short(n):42s} {cname:28s} {val:20.0f}  ({cnt} dispatches)")
+            print(f"  {short(n):58s} {cname:28s} {val:20.0f}  ({cnt} dispatches)")
 
 
 if __name__ == "__main__":
