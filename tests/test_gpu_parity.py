@@ -329,6 +329,48 @@ def test_stack_overflow_area_gives_the_same_image(gpu_ctx, golden_dir, name, mon
     assert np.array_equal(want, got) and np.array_equal(want_ids, got_ids)
 
 
+@pytest.mark.parametrize("name", ["book_cover", "material_demo"])
+def test_sphere_only_kernel_gives_the_plain_kernels_image(gpu_ctx, golden_dir, name, monkeypatch):
+    """Scenes of plain spheres run a trace kernel of their own (32-byte leaf slots in LDS, one-case
+    leaf test and hit record); MI355RT_SPHERES_KERNEL=0 sends them through the plain one.  Same
+    image, same operation counts, and both are the oracle's image."""
+    import pyoracle as po
+    scene, g = load(golden_dir, name)
+    w, h = scene.width, scene.height
+    depth = scene.max_depth
+    gpu_ctx.upload(scene)
+    a, sa = gpu_ctx.render(gpu_ctx.params(w, h, 0, 5, depth, seed=6), dtype=np.float64, stats=True)
+    monkeypatch.setenv("MI355RT_SPHERES_KERNEL", "0")
+    gpu_ctx.upload(scene)
+    b, sb = gpu_ctx.render(gpu_ctx.params(w, h, 0, 5, depth, seed=6), dtype=np.float64, stats=True)
+    monkeypatch.delenv("MI355RT_SPHERES_KERNEL")
+    gpu_ctx.upload(scene)
+    assert np.array_equal(a, b)
+    assert list(sa[:20]) == list(sb[:20])
+    ref = po.Oracle(scene.view_ptr).render(po.make_params(w, h, 0, 5, depth, 6), po.MODE_ITERATIVE, threads=8)
+    assert np.array_equal(a, ref)
+
+
+@pytest.mark.parametrize("name", ["perlin", "globe", "book2", "checker_mirror"])
+def test_textured_tail_gives_the_image_of_the_deferred_kernel(gpu_ctx, golden_dir, name, monkeypatch):
+    """Once few paths are left, a scene with procedural or image textures finishes them in one
+    launch that shades such hits in place; without it (MI355RT_TEXTURED_TAIL=0) every bounce runs
+    the trace kernel and the deferred shade kernel.  Same paths, same draws: the same numbers."""
+    scene, g = load(golden_dir, name)
+    w, h = scene.width, scene.height
+    depth = scene.max_depth
+    assert depth > 9  # (the live count is looked at after the eighth bounce)
+    gpu_ctx.upload(scene)
+    a = gpu_ctx.render(gpu_ctx.params(w, h, 0, 4, depth, seed=8), dtype=np.float64)
+    monkeypatch.setenv("MI355RT_TEXTURED_TAIL", "0")
+    gpu_ctx.upload(scene)
+    b = gpu_ctx.render(gpu_ctx.params(w, h, 0, 4, depth, seed=8), dtype=np.float64)
+    monkeypatch.delenv("MI355RT_TEXTURED_TAIL")
+    gpu_ctx.upload(scene)
+    assert np.array_equal(a, b)
+    assert a.max() > 0
+
+
 def test_headline_size_properties(gpu_ctx, golden_dir):
     """book_cover at 1920x1080, 1024 spp (the benchmark's workload): the sample range splits
     additively, a window is the same numbers as that region of the frame, and the window equals
