@@ -125,7 +125,16 @@ struct PassInfo {
   uint32_t samples;            // samples per pixel in this pass
   uint32_t tiled;              // window pixels are numbered 8x8 tile by tile (by_ww divides by tiles per row)
   uint64_t seed;
+  // Per 8x8 tile of the window, what its camera rays can meet (tile_list_kernel), or null: tile_words
+  // words a tile, [0] the number of leaf slots that follow or kTileWalk; sphere-only scenes: then, from
+  // word 16 on, centre and radius of each (so the first bounce reads one block and no record).
+  const uint32_t* tile_lists;
+  uint32_t tile_words;
 };
+const uint32_t kTileListWords = 16;          // header: count + up to 15 leaf slots
+const uint32_t kTileSphereMax = 14;          // sphere-only scenes: at most this many, 32 bytes of data each
+const uint32_t kTileSphereWords = 16 + 8 * kTileSphereMax;  // 128 words = 512 bytes a tile
+const uint32_t kTileWalk = 0xFFFFFFFFu;
 
 RT_DEV uint32_t lane_id() { return __lane_id(); }
 
@@ -609,6 +618,223 @@ shade_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps, uint32_t bounce, uint3
   if (STATS) flush_stats(st, g_stats);
 }
 
+// ------------------------------------------------------- camera-ray tile lists
+// The camera rays of one 8x8 tile of pixels, over every jitter, lens and time sample, stay inside
+// a thin beam; which leaf slots that beam can reach does not depend on the sample.  One thread per
+// tile walks the hierarchy once per render call with a conservative beam-against-box test and writes
+// the (few) leaf slots down; the first bounce of every one of the call's samples then tests its
+// tile's slots, wave-uniform, instead of walking the hierarchy per ray.  Closest hit over a
+// superset of what a ray can meet, by (t, rank): the same answer as the walk's.
+//
+// The beam.  Camera::get_ray (camera.rs:22-36) gives X(t) = O' + t (F - O') with O' = O + e,
+// e = u rd.x R + v rd.y R, |rd| < 1, and F = lower_left + s horizontal + t' vertical on the tile's
+// (s, t') rectangle (main.rs:91-93 with the jitter in [0, 1)).  With g = F - O:
+//   X - O = (1 - t) e + t g.
+// a = unit(u x v) is perpendicular to every e, so depth a.(X - O) = t (a.g); g ranges over the
+// tile's parallelogram, a.g between its corner values.  A side plane k of the pyramid from O
+// through the parallelogram (unit inward normal n_k, n_k.g >= 0 on the tile) sees
+//   n_k.(X - O) >= -|1 - t| |e| >= -|1 - t| R',   R' = R sqrt(largest eigenvalue of [[u.u u.v][u.v v.v]]).
+// A box is out of reach if it lies behind the lens plane, or if for some k all of it is further
+// outside plane k than R' max |1 - t| over the t its depth range allows.  Every quantity carries a
+// relative pad of 1e-9 against rounding; anything degenerate sends the tile to the walk.
+struct TileBeam {
+  double o[3], a[3], n[4][3];
+  double g_min, g_max, r_lens;
+  bool ok;
+};
+RT_DEV TileBeam tile_beam(const rt_camera& c, const PassInfo& ps, uint32_t tile) {
+  TileBeam b;
+  b.ok = false;
+  const uint32_t per_row = ps.ww >> 3;
+  const uint32_t ty = tile / per_row, tx = tile - ty * per_row;
+  const double x_lo = (double)(ps.x0 + 8u * tx), y_lo = (double)(ps.y0 + 8u * ty);
+  const double pad = 1e-9;
+  const double s0 = x_lo / ((double)ps.width - 1.0) - pad, s1 = (x_lo + 8.0) / ((double)ps.width - 1.0) + pad;
+  const double t0 = ((double)ps.height - (y_lo + 7.0)) / ((double)ps.height - 1.0) - pad;
+  const double t1 = ((double)ps.height - y_lo + 1.0) / ((double)ps.height - 1.0) + pad;
+  V3 o = v3(c.origin), ll = v3(c.lower_left), hz = v3(c.horizontal), vt = v3(c.vertical), u = v3(c.u), v = v3(c.v);
+  V3 a = v3(u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x);
+  const double la = vlen(a);
+  if (!(la > 0.0)) return b;
+  a = vscale(a, 1.0 / la);
+  // corners of the tile on the focal plane, relative to O, in order around the parallelogram
+  const double ss[4] = {s0, s1, s1, s0}, tt[4] = {t0, t0, t1, t1};
+  V3 g[4];
+  double gmin = 0.0, gmax = 0.0;
+  for (int k = 0; k < 4; ++k) {
+    g[k] = vsub(vadd(vadd(ll, vscale(hz, ss[k])), vscale(vt, tt[k])), o);
+    const double d = vdot(a, g[k]);
+    gmin = k == 0 ? d : fmin(gmin, d);
+    gmax = k == 0 ? d : fmax(gmax, d);
+  }
+  if (gmax < 0.0) {  // (u x v points backwards: turn it round)
+    a = vneg(a);
+    const double lo = -gmax, hi = -gmin;
+    gmin = lo;
+    gmax = hi;
+  }
+  if (!(gmin > 0.0) || !(gmax < 1e300)) return b;
+  const V3 centre = vadd(vadd(g[0], g[1]), vadd(g[2], g[3]));
+  for (int k = 0; k < 4; ++k) {
+    const V3 p = g[k], q = g[(k + 1) & 3];
+    V3 n = v3(p.y * q.z - p.z * q.y, p.z * q.x - p.x * q.z, p.x * q.y - p.y * q.x);
+    const double ln = vlen(n);
+    if (!(ln > 0.0)) return b;
+    n = vscale(n, 1.0 / ln);
+    if (vdot(n, centre) < 0.0) n = vneg(n);
+    // every corner on the inner side (two of them on the plane, up to rounding)
+    for (int j = 0; j < 4; ++j)
+      if (!(vdot(n, g[j]) >= -1e-9 * vlen(g[j]))) return b;
+    b.n[k][0] = n.x;
+    b.n[k][1] = n.y;
+    b.n[k][2] = n.z;
+  }
+  const double uu = vdot(u, u), vv = vdot(v, v), uv = vdot(u, v);
+  const double half = 0.5 * (uu - vv);
+  const double eig = 0.5 * (uu + vv) + sqrt(half * half + uv * uv);
+  b.r_lens = fabs(c.lens_radius) * sqrt(eig) * (1.0 + 1e-9);
+  if (!(b.r_lens < 1e300)) return b;
+  b.o[0] = o.x; b.o[1] = o.y; b.o[2] = o.z;
+  b.a[0] = a.x; b.a[1] = a.y; b.a[2] = a.z;
+  b.g_min = gmin * (1.0 - 1e-9);
+  b.g_max = gmax * (1.0 + 1e-9);
+  b.ok = true;
+  return b;
+}
+// Can no camera ray of the beam reach the box?  (NaN anywhere, e.g. from an infinite box: false.)
+RT_DEV bool beam_misses_box(const TileBeam& b, const float* lo, const float* hi) {
+  double dmin = 0.0, dmax = 0.0;
+  for (int k = 0; k < 3; ++k) {
+    const double p = b.a[k] * ((double)lo[k] - b.o[k]), q = b.a[k] * ((double)hi[k] - b.o[k]);
+    dmin += fmin(p, q);
+    dmax += fmax(p, q);
+  }
+  const double slack = 1e-9 * (fabs(dmin) + fabs(dmax));
+  if (dmax + slack < 0.0) return true;  // behind the lens plane: t > 0 means positive depth
+  const double t_lo = fmax(dmin - slack, 0.0) / b.g_max, t_hi = (dmax + slack) / b.g_min;
+  const double margin = b.r_lens * fmax(fabs(1.0 - t_lo), fabs(1.0 - t_hi));
+  for (int k = 0; k < 4; ++k) {
+    double reach = 0.0, size = 0.0;
+    for (int j = 0; j < 3; ++j) {
+      const double p = b.n[k][j] * ((double)lo[j] - b.o[j]), q = b.n[k][j] * ((double)hi[j] - b.o[j]);
+      reach += fmax(p, q);
+      size += fmax(fabs(p), fabs(q));
+    }
+    if (reach < -(margin * (1.0 + 1e-9) + 1e-9 * size)) return true;
+  }
+  return false;
+}
+template <bool SPHERES>
+__global__ void __launch_bounds__(kBlock)
+tile_list_kernel(DeviceScene sc, PassInfo ps, uint32_t* lists, uint32_t n_tiles) {
+  const uint32_t tile = blockIdx.x * kBlock + threadIdx.x;
+  if (tile >= n_tiles) return;
+  constexpr uint32_t kMax = SPHERES ? kTileSphereMax : kTileListWords - 1u;
+  uint32_t* out = lists + (size_t)tile * (SPHERES ? kTileSphereWords : kTileListWords);
+  const TileBeam beam = tile_beam(sc.cam, ps, tile);
+  if (!beam.ok) {
+    out[0] = kTileWalk;
+    return;
+  }
+  uint32_t count = 0;
+  if (sc.n_nodes != 0) {
+    const rt_bvh_node* nodes = (const rt_bvh_node*)sc.nodes;
+    uint32_t stack[64];
+    uint32_t sp = 0, cur = sc.root_code;  // (the root's own box is not tested, as in the walk)
+    for (;;) {
+      if (cur & 1u) {
+        const uint32_t first = cur >> 4, n = ((cur >> 1) & 7u) + 1u;
+        for (uint32_t k = 0; k < n; ++k) {
+          if (count == kMax) {
+            out[0] = kTileWalk;
+            return;
+          }
+          if (SPHERES) {  // centre and radius beside the slot
+            const double* p = sc.prims[first + k].p;
+            double* data = (double*)(out + kTileListWords) + 4u * count;
+            data[0] = p[0];
+            data[1] = p[1];
+            data[2] = p[2];
+            data[3] = p[3];
+          }
+          out[1u + count++] = first + k;
+        }
+      } else {
+        const uint32_t first = cur >> (kWideBits + 1u), n = ((cur >> 1) & (kWide - 1u)) + 1u;
+        for (uint32_t k = 0; k < n; ++k) {
+          const rt_bvh_node rec = nodes[first + k];
+          if (beam_misses_box(beam, rec.lo, rec.hi)) continue;
+          if (sp == 64u) {
+            out[0] = kTileWalk;
+            return;
+          }
+          stack[sp++] = rec.a;  // (the device copy holds the entry code here)
+        }
+      }
+      if (sp == 0u) break;
+      cur = stack[--sp];
+    }
+  }
+  out[0] = count;
+}
+
+// world.hit(ray, tmin..inf) over the leaf slots of a tile's list (wave-uniform addresses):
+// HittableList::hit's first minimum by (t, rank), as closest_hit's.  `list` points at the tile's
+// first slot word.  Plain scenes only (no media, no box chains: their kernels do not use lists).
+// SPHERES: centre and radius of candidate k sit in the tile's own block, 32 bytes each after the
+// 16-word header; the next candidate's are fetched while this one is tested, and no load depends
+// on another.
+template <bool SPHERES>
+RT_DEV Closest closest_of_list(const DeviceScene& sc, const uint32_t* list, uint32_t count, V3 o, V3 d, double time,
+                               double tmin) {
+  const double inf = __longlong_as_double(0x7FF0000000000000ll);
+  Closest best;
+  best.t = inf;
+  best.item = kNoPrim;
+  best.kind = 0;
+  const double dd = vlen2(d);
+  Stats unused;
+  if (SPHERES) {
+    union Q {
+      f32x4 q[2];
+      double p[4];
+    };
+    const f32x4* data = (const f32x4*)(list - 1 + kTileListWords);
+    Q next;
+    next.q[0] = data[0];
+    next.q[1] = data[1];
+    uint32_t best_k = kNoPrim;
+    for (uint32_t k = 0; k < count; ++k) {
+      const Q cur = next;
+      if (k + 1u < count) {
+        next.q[0] = data[2u * k + 2u];
+        next.q[1] = data[2u * k + 3u];
+      }
+      double t;
+      if (!sphere_t<false>(v3(cur.p[0], cur.p[1], cur.p[2]), cur.p[3], o, d, dd, tmin, inf, t, unused)) continue;
+      if (t < best.t || (t == best.t && best_k != kNoPrim && sc.ranks[list[k]] < sc.ranks[list[best_k]])) {
+        best.t = t;
+        best_k = k;
+      }
+    }
+    if (best_k != kNoPrim) best.item = list[best_k];
+    return best;
+  }
+  for (uint32_t k = 0; k < count; ++k) {
+    const uint32_t slot = list[k];
+    const DPrim whole = sc.prims[slot];
+    double t;
+    bool overhang = false;
+    if (!base_prim_t<false>(sc, whole, o, d, dd, time, tmin, inf, t, unused, overhang)) continue;
+    if (t < best.t || (t == best.t && best.item != kNoPrim && sc.ranks[slot] < sc.ranks[best.item])) {
+      best.t = t;
+      best.item = slot;
+      best.kind = whole.kind;
+    }
+  }
+  return best;
+}
+
 // ------------------------------------------------------------- trace (fused)
 // Extend and shade in one kernel, for scenes whose shading is cheap (only
 // SolidColor textures): the ray stays in registers between the traversal and the
@@ -737,6 +963,16 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
     uint32_t next_base = TAIL ? base + stride : base + kTripStep, next_trip = trip_in_run + 1u;
     const bool draws = !TAIL && (next_trip == kTripsPerGrab || next_base >= n_live);
     if (!draws && next_base > base) path_ahead = live.template fetch<FIRST>(next_base, threadIdx.x & 63u);
+    // the first bounce: the leaf slots this trip's tile of pixels can meet, if the call made lists
+    // (a trip is 64 consecutive paths of one sample = one 8x8 tile: wave-uniform)
+    uint32_t tile_count = kTileWalk;
+    const uint32_t* tile_list = nullptr;
+    if (FIRST && !MEDIA && !STATS && ps.tile_lists != nullptr) {
+      const uint32_t ubase = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+      const uint32_t tile = (ubase - fastdiv(ubase, ps.by_pixels) * ps.n_pixels) >> 6;
+      tile_list = ps.tile_lists + (size_t)tile * ps.tile_words + 1u;
+      tile_count = tile_list[-1];
+    }
     uint32_t bounce = first_bounce;
     bool survives, deferred = false;
     do {
@@ -771,7 +1007,11 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
         stat<STATS>(st, RT_STAT_RAYS);
         RT_LP(st, LP_RAY);
         RT_TICK(st, LP_T_SETUP, tick);
-        Closest h = closest_hit<STATS, MEDIA, MEDIA, OVERFLOW, SPHERES>(sc, lds, o, d, time, 0.001, key, st);
+        Closest h;
+        if (FIRST && !MEDIA && !STATS && tile_count != kTileWalk)
+          h = closest_of_list<SPHERES>(sc, tile_list, tile_count, o, d, time, 0.001);
+        else
+          h = closest_hit<STATS, MEDIA, MEDIA, OVERFLOW, SPHERES>(sc, lds, o, d, time, 0.001, key, st);
         RT_TICK(st, LP_T_TRAVERSE, tick);
         // ... and starts from beta = 1, L = 0
         V3 beta = v3(1.0, 1.0, 1.0);
@@ -1070,6 +1310,8 @@ struct rt_ctx {
   bool solid = true;       // every texture is a SolidColor
   bool general = false;    // the scene needs the general trace kernel
   bool textured_tail = true;  // scenes with procedural or image textures run the tail launch too (MI355RT_TEXTURED_TAIL=0: no)
+  bool tile_lists_on = true;  // camera-ray tile lists for the plain kernels (MI355RT_TILE_LISTS=0: no)
+  DeviceArray<uint32_t> tile_lists;
   bool spheres = false;    // every leaf slot is a plain sphere without wrappers: the sphere-only trace kernel
   uint32_t counters_depth = 0;
   DeviceArray<double> accum;
@@ -1525,6 +1767,25 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats, d
   }
   const PathBuffers& pb = in_scratch ? scratch_pb : ctx->pb;
   const uint32_t max_grid = ctx->n_cus * ctx->blocks_per_cu;
+  // What each 8x8 tile's camera rays can meet, once per call (see tile_list_kernel): the plain
+  // kernels' first bounce tests those few leaf slots instead of walking the hierarchy per ray.
+  // Not for the instrumented kernels (their counts are the walk's), nor where nothing may be allocated.
+  ps.tile_lists = nullptr;
+  if (fused && !general && ps.tiled && ctx->tile_lists_on && !want_stats && !in_scratch) {
+    const uint32_t n_tiles = (ps.ww >> 3) * (ps.wh >> 3);
+    ps.tile_words = ctx->spheres ? kTileSphereWords : kTileListWords;
+    const size_t words = (size_t)n_tiles * ps.tile_words;
+    if (ctx->tile_lists.n < words) {
+      ctx->tile_lists.release();
+      RT_HIP(ctx, hipMalloc((void**)&ctx->tile_lists.p, words * sizeof(uint32_t)));
+      ctx->tile_lists.n = words;
+    }
+    if (ctx->spheres)
+      tile_list_kernel<true><<<blocks_for(n_tiles), kBlock, 0, ctx->stream>>>(ctx->ds, ps, ctx->tile_lists.p, n_tiles);
+    else
+      tile_list_kernel<false><<<blocks_for(n_tiles), kBlock, 0, ctx->stream>>>(ctx->ds, ps, ctx->tile_lists.p, n_tiles);
+    ps.tile_lists = ctx->tile_lists.p;
+  }
   rt_ctx* const report = ctx->progress_to ? ctx->progress_to : ctx;
   if (!ctx->progress_to) {  // (a group sets its totals itself)
     ctx->progress_done = 0;
@@ -1905,6 +2166,7 @@ static int upload_flat(rt_ctx* ctx) {
     if (const char* e = getenv("MI355RT_STACK_CAP")) stack_cap = (uint32_t)strtoul(e, nullptr, 10);
     if (const char* e = getenv("MI355RT_TAIL_PATHS")) ctx->tail_paths = (uint32_t)strtoul(e, nullptr, 10);
     if (const char* e = getenv("MI355RT_TEXTURED_TAIL")) ctx->textured_tail = atoi(e) != 0;
+    if (const char* e = getenv("MI355RT_TILE_LISTS")) ctx->tile_lists_on = atoi(e) != 0;
     ctx->blocks_per_cu = 16u;
     if (const char* e = getenv("MI355RT_BLOCKS_PER_CU"))
       ctx->blocks_per_cu = std::max(1u, (uint32_t)strtoul(e, nullptr, 10));
@@ -2304,6 +2566,7 @@ void rt_destroy(rt_ctx* ctx) {
   ctx->texels.release();
   ctx->chain_boxes.release();
   ctx->stack_overflow.release();
+  ctx->tile_lists.release();
   ctx->chain_ranges.release();
   ctx->accum.release();
   ctx->staging.release();

@@ -371,6 +371,68 @@ def test_textured_tail_gives_the_image_of_the_deferred_kernel(gpu_ctx, golden_di
     assert a.max() > 0
 
 
+@pytest.mark.parametrize("name,w,h,window", [("book_cover", 320, 184, None), ("book_cover", 640, 360, (200, 96, 64, 40)),
+                                              ("material_demo", 160, 96, None), ("motion_blur", 160, 56, None),
+                                              ("cornell", 96, 96, None), ("refraction", 160, 56, (8, 8, 48, 40)),
+                                              ("checker_mirror", 160, 120, None)])
+def test_camera_ray_tile_lists_give_the_walks_image(gpu_ctx, golden_dir, name, w, h, window, monkeypatch):
+    """The first bounce of a plain scene tests the leaf slots its 8x8 tile of pixels can meet (made
+    once per call from a conservative beam) instead of walking the hierarchy per ray;
+    MI355RT_TILE_LISTS=0 walks.  Same closest hits, so the same numbers; and both are the oracle's."""
+    import pyoracle as po
+    scene, g = load(golden_dir, name)
+    scene.set_image(w, h)
+    depth = min(scene.max_depth, 12)
+    gpu_ctx.upload(scene)
+    a = gpu_ctx.render(gpu_ctx.params(w, h, 0, 6, depth, seed=12, window=window), dtype=np.float64)
+    monkeypatch.setenv("MI355RT_TILE_LISTS", "0")
+    gpu_ctx.upload(scene)
+    b = gpu_ctx.render(gpu_ctx.params(w, h, 0, 6, depth, seed=12, window=window), dtype=np.float64)
+    monkeypatch.delenv("MI355RT_TILE_LISTS")
+    gpu_ctx.upload(scene)
+    assert np.array_equal(a, b)
+    ref = po.Oracle(scene.view_ptr).render(po.make_params(w, h, 0, 6, depth, 12, window=window),
+                                           po.MODE_ITERATIVE, threads=8)
+    if name == "checker_mirror":  # (sin in the checker texture: libm's last place)
+        assert np.allclose(a, ref, rtol=1e-9, atol=1e-12)
+    else:
+        assert np.array_equal(a, ref)
+
+
+@pytest.mark.parametrize("aperture,focus,fov,look_from", [(2.0, 2.0, 80.0, (0.3, 0.4, 3.0)), (0.8, 12.0, 35.0, (6.0, 1.0, 2.0)),
+                                                         (4.0, 0.7, 100.0, (0.0, 0.2, 1.5)), (0.0, 5.0, 20.0, (0.0, 9.0, 0.1))])
+def test_tile_lists_under_wide_lenses(gpu_ctx, aperture, focus, fov, look_from):
+    """Cameras that strain the beam bound: lenses wider than the objects, a focal plane in front of,
+    inside and behind them, steep view angles.  Spheres and a rotated, translated box; the image
+    must be the oracle's, bit for bit (a leaf slot missing from a tile's list would show)."""
+    import random
+    import pyoracle as po
+    from raytracer_amd.scene import HostScene
+    r = random.Random(7)
+    objs = ['Sphere(center: (0, -100.5, 0), radius: 100, material: Shared("grey"))']
+    for _ in range(40):
+        objs.append('Sphere(center: (%.3f, %.3f, %.3f), radius: %.3f, material: Shared("grey"))'
+                    % (r.uniform(-3, 3), r.uniform(-0.4, 1.5), r.uniform(-4, 2), r.uniform(0.05, 0.5)))
+    objs.append('Translate(offset: (1.0, 0.2, -1.0), hittable: RotateY(angle: 30, hittable: '
+                'Cuboid(size: (0.6, 0.8, 0.6), material: Shared("grey"))))')
+    text = """Scene(
+  image: (width: 96, height: 64, samples_per_pixel: 2, max_depth: 6),
+  camera: (look_from: (%s, %s, %s), look_at: (0, 0, -1), vertical_fov: %s, aperture: %s, focus_distance: %s),
+  background: (0.6, 0.7, 1.0),
+  materials: { "grey": Lambertian(albedo: Solid(0.5, 0.5, 0.5)) },
+  objects: [
+    %s
+  ]
+)""" % (*look_from, fov, aperture, focus, ",\n    ".join(objs))
+    scene = HostScene.load_ron_text(text)
+    gpu_ctx.upload(scene)
+    w, h = scene.width, scene.height
+    img = gpu_ctx.render(gpu_ctx.params(w, h, 0, 8, scene.max_depth, seed=3), dtype=np.float64)
+    ref = po.Oracle(scene.view_ptr).render(po.make_params(w, h, 0, 8, scene.max_depth, 3), po.MODE_ITERATIVE, threads=8)
+    assert np.array_equal(img, ref)
+    assert img.max() > 0
+
+
 def test_headline_size_properties(gpu_ctx, golden_dir):
     """book_cover at 1920x1080, 1024 spp (the benchmark's workload): the sample range splits
     additively, a window is the same numbers as that region of the frame, and the window equals
