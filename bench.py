@@ -37,7 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from raytracer_amd import abi  # noqa: E402
-from raytracer_amd.dist import render_sharded  # noqa: E402
+from raytracer_amd.dist import gather_rank_times, render_sharded  # noqa: E402
 from raytracer_amd.render import Context  # noqa: E402
 from raytracer_amd.scene import HostScene  # noqa: E402
 
@@ -200,13 +200,7 @@ def main():
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        # what each rank spent inside the library (its share of the samples) and, the rest of its
-        # step, in the reduce and the waits around it: so that a scaling run explains itself
-        mine = torch.tensor([render_s[0], elapsed - render_s[0]], dtype=torch.float64, device=device)
-        gathered = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(gathered, mine)
-        per_rank = [[1e3 * float(g[0]) / max(args.steps, 1), 1e3 * float(g[1]) / max(args.steps, 1)]
-                    for g in gathered]
+        per_rank = gather_rank_times(dist, world, render_s[0], elapsed, args.steps, device)
         elapsed = float(t.item())
 
     pixel_samples = float(args.width) * args.height * args.spp * args.steps
@@ -233,8 +227,7 @@ def main():
     }
 
     if per_rank is not None:
-        result["per_rank_ms_per_step"] = {"render": [r[0] for r in per_rank],
-                                          "reduce_and_wait": [r[1] for r in per_rank]}
+        result["per_rank_ms_per_step"] = per_rank
 
     if world == 1 and rank == 0:
         # operation counts of the work of one step, from the instrumented kernels (the headline

@@ -39,3 +39,20 @@ def render_sharded(render_fn, out, sample_begin, sample_end, rank, world, dist=N
         work.wait()
         settle()
     return lo, hi
+
+
+def gather_rank_times(dist, world, render_s, step_s, steps, device=None):
+    """What every rank spent per step inside the library (its share of the samples) and, the rest
+    of its step, in the reduce and the waits around it, in milliseconds: rank-ordered lists
+    {"render": [...], "reduce_and_wait": [...]} on every rank.  A scaling run then explains itself:
+    a slow rank shows in `render`, a slow collective or an uneven split in `reduce_and_wait`."""
+    import torch
+    mine = torch.tensor([render_s, step_s - render_s], dtype=torch.float64, device=device)
+    if dist is None or world <= 1:
+        gathered = [mine]
+    else:
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+    per = 1e3 / max(steps, 1)
+    return {"render": [per * float(g[0]) for g in gathered],
+            "reduce_and_wait": [per * float(g[1]) for g in gathered]}

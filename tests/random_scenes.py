@@ -58,7 +58,9 @@ def _wrapped(r, textured, depth=0):
     return inner
 
 
-def random_scene(seed, n_objects=None, textured=False, width=48, height=32):
+def random_scene(seed, n_objects=None, textured=False, width=48, height=32, wide_lens=False):
+    """wide_lens: lenses up to several units across and focal planes anywhere from in front of the
+    objects to far behind them (drawn from a generator of their own: the scene is the same otherwise)."""
     r = random.Random(seed)
     n = n_objects if n_objects is not None else r.choice([1, 3, 8, 20, 60, 300])
     objs = []
@@ -73,6 +75,11 @@ def random_scene(seed, n_objects=None, textured=False, width=48, height=32):
         _v(r, -9, 9), _v(r, -1, 1), round(r.uniform(25, 70), 1), r.choice([0, 0, round(r.uniform(0, 0.3), 3)]))
     if r.random() < 0.5:
         cam += ", shutter_time: (0, 1)"
+    if wide_lens:
+        rl = random.Random(seed * 7919 + 13)
+        cam = cam[:cam.rindex("aperture:")] + "aperture: %s, focus_distance: %s" % (
+            round(rl.choice([rl.uniform(0.3, 1.0), rl.uniform(1.0, 4.0)]), 3), round(rl.uniform(0.4, 15.0), 3)) + (
+            ", shutter_time: (0, 1)" if "shutter_time" in cam else "")
     return """Scene(
   image: (width: %d, height: %d, samples_per_pixel: 2, max_depth: %d),
   camera: (%s),

@@ -5,7 +5,7 @@ import sys
 import numpy as np
 import pytest
 
-from raytracer_amd.dist import render_sharded, shard_samples
+from raytracer_amd.dist import gather_rank_times, render_sharded, shard_samples
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -40,6 +40,10 @@ def _worker(rank, world, port, out_dir):
 
     out = torch.zeros((h, w, 3), dtype=torch.float32)
     lo, hi = render_sharded(render_fn, out, 0, spp, rank, world, dist)
+    # the per-rank timing report of the benchmark: every rank gets every rank's figures, in rank order
+    times = gather_rank_times(dist, world, 0.010 * (rank + 1), 0.050, 5)
+    assert np.allclose(times["render"], [2.0 * (k + 1) for k in range(world)])
+    assert np.allclose(times["reduce_and_wait"], [10.0 - 2.0 * (k + 1) for k in range(world)])
     if rank == 0:
         np.save(os.path.join(out_dir, "sharded.npy"), out.numpy())
     dist.barrier()

@@ -1,6 +1,6 @@
 """One-off differential run: many seeded random scenes, device against the CPU oracle.
 
-usage: python tools/fuzz_gpu.py first_seed count [textured]
+usage: python tools/fuzz_gpu.py first_seed count [textured] [wide]     (wide: lenses and focal planes that strain the tile beams)
 """
 import os
 import sys
@@ -18,11 +18,12 @@ from raytracer_amd.render import Context  # noqa: E402
 from raytracer_amd.scene import HostScene  # noqa: E402
 
 first, count = int(sys.argv[1]), int(sys.argv[2])
-textured = len(sys.argv) > 3
+textured = "textured" in sys.argv[3:]
+wide = "wide" in sys.argv[3:]
 ctx = Context(0)
 bad = 0
 for seed in range(first, first + count):
-    text = random_scene(seed, textured=textured, width=64, height=48)
+    text = random_scene(seed, textured=textured, width=64, height=48, wide_lens=wide)
     scene = HostScene.load_ron_text(text)
     ctx.upload(scene)
     w, h = scene.width, scene.height
