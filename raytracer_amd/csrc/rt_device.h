@@ -367,8 +367,38 @@ RT_DEV bool medium_t(const DeviceScene& sc, const DPrim& pr, V3 o, V3 d, double 
   const double inf = __longlong_as_double(0x7FF0000000000000ll);
   uint32_t first = (uint32_t)pr.p[1], count = (uint32_t)pr.p[2];
   double t1, t2;
-  if (!boundary_t<STATS>(sc, first, count, o, d, time, -inf, inf, t1, st)) return false;
-  if (!boundary_t<STATS>(sc, first, count, o, d, time, t1 + 0.0001, inf, t2, st)) return false;
+  const DPrim b0 = sc.boundary[first];
+  const uint32_t bkind = b0.kind & 15u;
+  if (count == 1u && ops_count(b0.ops) == 0u && (bkind == DP_SPHERE || bkind == DP_MOVING_SPHERE)) {
+    // A sphere as the boundary (every medium of the reference's scenes): boundary.hit(-inf..inf) and
+    // boundary.hit(t1 + 0.0001..inf) are Sphere::hit twice on the same ray, so the discriminant, its
+    // root and both quotients (sphere.rs:32-47) are the same numbers both times; they are formed
+    // once and each call's choice between them (sphere.rs:42-50) is made as that call would.
+    const int test_stat = bkind == DP_SPHERE ? RT_STAT_SPHERE_TESTS : RT_STAT_MSPHERE_TESTS;
+    stat<STATS>(st, test_stat);  // (counted as the two calls would count)
+    const V3 c = bkind == DP_SPHERE ? v3(b0.p[0], b0.p[1], b0.p[2]) : moving_center(sc, b0, time);
+    const double a = vlen2(d);
+    V3 oc = vsub(o, c);
+    double half_b = vdot(oc, d);
+    double cc = vlen2(oc) - b0.p[3] * b0.p[3];
+    double discrim = half_b * half_b - a * cc;
+    if (discrim < 0.0) return false;
+    stat<STATS>(st, RT_STAT_SPHERE_ROOTS);
+    double sqrtd = sqrt(discrim);
+    const double near = (-half_b - sqrtd) / a, far = (-half_b + sqrtd) / a;
+    if (in_range(near, -inf, inf)) t1 = near;
+    else if (in_range(far, -inf, inf)) t1 = far;
+    else return false;
+    stat<STATS>(st, test_stat);
+    stat<STATS>(st, RT_STAT_SPHERE_ROOTS);
+    const double lo2 = t1 + 0.0001;
+    if (in_range(near, lo2, inf)) t2 = near;
+    else if (in_range(far, lo2, inf)) t2 = far;
+    else return false;
+  } else {
+    if (!boundary_t<STATS>(sc, first, count, o, d, time, -inf, inf, t1, st)) return false;
+    if (!boundary_t<STATS>(sc, first, count, o, d, time, t1 + 0.0001, inf, t2, st)) return false;
+  }
   if (t1 < tmin) t1 = tmin;
   if (t2 > tmax) t2 = tmax;
   if (t1 >= t2) return false;
