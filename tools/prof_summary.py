@@ -10,7 +10,7 @@ import sys
 
 def short(name):
     for k in ("trace_kernel", "extend_kernel", "shade_kernel", "raygen_kernel", "resolve_kernel", "first_hit_kernel",
-              "to_float_kernel"):
+              "to_float_kernel", "tile_list_kernel", "device_records_kernel"):
         if k in name:
             tail = name[name.index(k):].split("(")[0]
             return tail[:56].rstrip(">").rstrip()
