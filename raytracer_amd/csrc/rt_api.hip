@@ -780,13 +780,15 @@ tile_list_kernel(DeviceScene sc, PassInfo ps, uint32_t* lists, uint32_t n_tiles)
 
 // world.hit(ray, tmin..inf) over the leaf slots of a tile's list (wave-uniform addresses):
 // HittableList::hit's first minimum by (t, rank), as closest_hit's.  `list` points at the tile's
-// first slot word.  Plain scenes only (no media, no box chains: their kernels do not use lists).
+// first slot word.
 // SPHERES: centre and radius of candidate k sit in the tile's own block, 32 bytes each after the
 // 16-word header; the next candidate's are fetched while this one is tested, and no load depends
 // on another.
-template <bool SPHERES>
+// MEDIA: constant media and records tied to the reference's box chain are settled in place
+// (closest_hit sets them aside only because its walk's state is alive around them).
+template <bool SPHERES, bool MEDIA>
 RT_DEV Closest closest_of_list(const DeviceScene& sc, const uint32_t* list, uint32_t count, V3 o, V3 d, double time,
-                               double tmin) {
+                               double tmin, const DrawKey& key) {
   const double inf = __longlong_as_double(0x7FF0000000000000ll);
   Closest best;
   best.t = inf;
@@ -824,9 +826,20 @@ RT_DEV Closest closest_of_list(const DeviceScene& sc, const uint32_t* list, uint
     const uint32_t slot = list[k];
     const DPrim whole = sc.prims[slot];
     double t;
-    bool overhang = false;
-    if (!base_prim_t<false>(sc, whole, o, d, dd, time, tmin, inf, t, unused, overhang)) continue;
-    if (t < best.t || (t == best.t && best.item != kNoPrim && sc.ranks[slot] < sc.ranks[best.item])) {
+    bool hit;
+    if ((whole.kind & 15u) == DP_MEDIUM) {
+      hit = false;  // (a scene's media are skipped by the kernels that do not carry them)
+      if (MEDIA) {
+        hit = medium_t<false>(sc, whole, o, d, time, tmin, inf, key, t, unused);
+        if (hit && (whole.kind & kChainBit)) hit = reference_chain_passes(sc, (uint32_t)whole.p[3], o, d, tmin);
+      }
+    } else {
+      bool overhang = true;
+      hit = base_prim_t<false>(sc, whole, o, d, dd, time, tmin, inf, t, unused, overhang);
+      if (MEDIA && hit && (whole.kind & kChainBit) && overhang)
+        hit = reference_chain_passes(sc, (uint32_t)whole.p5, o, d, tmin);
+    }
+    if (hit && (t < best.t || (t == best.t && best.item != kNoPrim && sc.ranks[slot] < sc.ranks[best.item]))) {
       best.t = t;
       best.item = slot;
       best.kind = whole.kind;
@@ -967,7 +980,7 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
     // (a trip is 64 consecutive paths of one sample = one 8x8 tile: wave-uniform)
     uint32_t tile_count = kTileWalk;
     const uint32_t* tile_list = nullptr;
-    if (FIRST && !MEDIA && !STATS && ps.tile_lists != nullptr) {
+    if (FIRST && !STATS && ps.tile_lists != nullptr) {
       const uint32_t ubase = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
       const uint32_t tile = (ubase - fastdiv(ubase, ps.by_pixels) * ps.n_pixels) >> 6;
       tile_list = ps.tile_lists + (size_t)tile * ps.tile_words + 1u;
@@ -1008,8 +1021,8 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
         RT_LP(st, LP_RAY);
         RT_TICK(st, LP_T_SETUP, tick);
         Closest h;
-        if (FIRST && !MEDIA && !STATS && tile_count != kTileWalk)
-          h = closest_of_list<SPHERES>(sc, tile_list, tile_count, o, d, time, 0.001);
+        if (FIRST && !STATS && tile_count != kTileWalk)
+          h = closest_of_list<SPHERES, MEDIA>(sc, tile_list, tile_count, o, d, time, 0.001, key);
         else
           h = closest_hit<STATS, MEDIA, MEDIA, OVERFLOW, SPHERES>(sc, lds, o, d, time, 0.001, key, st);
         RT_TICK(st, LP_T_TRAVERSE, tick);
@@ -1767,11 +1780,11 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats, d
   }
   const PathBuffers& pb = in_scratch ? scratch_pb : ctx->pb;
   const uint32_t max_grid = ctx->n_cus * ctx->blocks_per_cu;
-  // What each 8x8 tile's camera rays can meet, once per call (see tile_list_kernel): the plain
+  // What each 8x8 tile's camera rays can meet, once per call (see tile_list_kernel): the fused
   // kernels' first bounce tests those few leaf slots instead of walking the hierarchy per ray.
   // Not for the instrumented kernels (their counts are the walk's), nor where nothing may be allocated.
   ps.tile_lists = nullptr;
-  if (fused && !general && ps.tiled && ctx->tile_lists_on && !want_stats && !in_scratch) {
+  if (fused && ps.tiled && ctx->tile_lists_on && !want_stats && !in_scratch) {
     const uint32_t n_tiles = (ps.ww >> 3) * (ps.wh >> 3);
     ps.tile_words = ctx->spheres ? kTileSphereWords : kTileListWords;
     const size_t words = (size_t)n_tiles * ps.tile_words;
@@ -1860,6 +1873,19 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats, d
       }
     }
     resolve_kernel<<<blocks_for(n_pix), kBlock, 0, ctx->stream>>>(pb, ps, accum);
+    if (getenv("MI355RT_DEBUG_LIVE")) {  // live paths after every bounce of this pass (a tail launch leaves its rows at zero)
+      std::vector<uint32_t> rows((size_t)p->max_depth * kCounterStride);
+      RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      RT_HIP(ctx, hipMemcpy(rows.data(), pb.counters, rows.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+      fprintf(stderr, "mi355rt: pass of %u samples, %u paths; live after bounce b:", ps.samples, ps.n_paths);
+      for (uint32_t b = 0; b < p->max_depth; ++b) {
+        uint64_t live = 0;
+        for (uint32_t q = 0; q < kSubQueues; ++q) live += rows[(size_t)b * kCounterStride + 32u * (1u + q)];
+        fprintf(stderr, " %llu", (unsigned long long)live);
+        if (live == 0) break;
+      }
+      fprintf(stderr, "\n");
+    }
     if (report->progress_fn) {
       // a pass counts once it has finished: wait for it (only callers that asked pay for this)
       RT_HIP(ctx, hipStreamSynchronize(ctx->stream));

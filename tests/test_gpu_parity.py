@@ -374,7 +374,8 @@ def test_textured_tail_gives_the_image_of_the_deferred_kernel(gpu_ctx, golden_di
 @pytest.mark.parametrize("name,w,h,window", [("book_cover", 320, 184, None), ("book_cover", 640, 360, (200, 96, 64, 40)),
                                               ("material_demo", 160, 96, None), ("motion_blur", 160, 56, None),
                                               ("cornell", 96, 96, None), ("refraction", 160, 56, (8, 8, 48, 40)),
-                                              ("checker_mirror", 160, 120, None)])
+                                              ("checker_mirror", 160, 120, None), ("book2", 160, 96, None),
+                                              ("medium_demo", 160, 96, (16, 8, 96, 64))])
 def test_camera_ray_tile_lists_give_the_walks_image(gpu_ctx, golden_dir, name, w, h, window, monkeypatch):
     """The first bounce of a plain scene tests the leaf slots its 8x8 tile of pixels can meet (made
     once per call from a conservative beam) instead of walking the hierarchy per ray;
@@ -393,7 +394,7 @@ def test_camera_ray_tile_lists_give_the_walks_image(gpu_ctx, golden_dir, name, w
     assert np.array_equal(a, b)
     ref = po.Oracle(scene.view_ptr).render(po.make_params(w, h, 0, 6, depth, 12, window=window),
                                            po.MODE_ITERATIVE, threads=8)
-    if name == "checker_mirror":  # (sin in the checker texture: libm's last place)
+    if name in ("checker_mirror", "book2", "medium_demo"):  # (sin, log10 and friends: libm's last place)
         assert np.allclose(a, ref, rtol=1e-9, atol=1e-12)
     else:
         assert np.array_equal(a, ref)
