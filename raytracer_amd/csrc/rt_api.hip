@@ -87,6 +87,15 @@ struct PathBuffers {
   uint32_t* bins;     // kBins queues of `capacity` entries (binned pipeline), or the one deferred queue
   uint32_t* counters; // (max_depth) x kCounterStride
   uint64_t capacity;
+  // Streamed path state (trace_kernel, scenes that defer nothing): ray and attenuation live at the
+  // path's POSITION IN THE LIVE QUEUE, not at its index.  A bounce reads positions of the set
+  // (bounce & 1) and writes its survivors to freshly reserved positions of the other set
+  // (ray_o, ray_d, beta are set 0; alt_* set 1), so both sides are dense whatever share of
+  // the pass is still alive.  Only sub-queue 0 is used; its counter is the end of the position space.
+  double4* alt_o;
+  double4* alt_d;
+  double4* alt_beta;
+  uint32_t stream;
 };
 
 // Division of a 32-bit number by an invariant divisor as one multiply-high and two shifts
@@ -863,6 +872,10 @@ RT_DEV Closest closest_of_list(const DeviceScene& sc, const uint32_t* list, uint
 #ifndef RT_WAVE_FLUSH_AT
 #define RT_WAVE_FLUSH_AT 128
 #endif
+#ifndef RT_STREAM_MIN_CHUNK
+#define RT_STREAM_MIN_CHUNK 128
+#endif
+const uint32_t kStreamMinChunk = RT_STREAM_MIN_CHUNK, kStreamMaxChunk = 1024;  // (powers of two, multiples of 64)
 const uint32_t kWaveFlushAt = RT_WAVE_FLUSH_AT;
 const uint32_t kWaveStage = kWaveFlushAt + 64;
 #ifndef RT_DEFER_FLUSH_AT
@@ -929,11 +942,29 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
   constexpr bool DEFER = !TAIL;  // (the tail shades everything in place; the host runs none for textured scenes)
   __shared__ uint32_t s_defer[DEFER ? (BLOCK / 64) * kDeferStage : 1];
   const LiveTrips live = live_trips(pb, first_bounce, ps.n_paths);  // (bounce 0: no queue, path = index)
-  uint32_t* next_live = next_live_queue(pb, first_bounce, blockIdx.x);
-  uint32_t* next_count = next_live_counter(pb, first_bounce, blockIdx.x);
+  uint32_t* next_live = next_live_queue(pb, first_bounce, pb.stream ? 0u : blockIdx.x);
+  uint32_t* next_count = next_live_counter(pb, first_bounce, pb.stream ? 0u : blockIdx.x);
   uint32_t* counters = pb.counters + (size_t)first_bounce * kCounterStride;
   const uint32_t n_live = live.end;  // (of the trip index space: see LiveTrips)
   if (blockIdx.x * (uint32_t)BLOCK >= n_live) return;
+  // Streamed state: where this bounce reads and writes rays and attenuations (the tail works in place).
+  const bool stream = pb.stream != 0u;
+  const bool in_alt = stream && (first_bounce & 1u), out_alt = stream && (TAIL ? in_alt : !in_alt);
+  const double4* const in_o = in_alt ? pb.alt_o : pb.ray_o;
+  const double4* const in_d = in_alt ? pb.alt_d : pb.ray_d;
+  const double4* const in_beta = in_alt ? pb.alt_beta : pb.beta;
+  double4* const out_o = out_alt ? pb.alt_o : pb.ray_o;
+  double4* const out_d = out_alt ? pb.alt_d : pb.ray_d;
+  double4* const out_beta = out_alt ? pb.alt_beta : pb.beta;
+  // A wave reserves output positions a chunk at a time (one atomic per chunk) and hands them to its
+  // survivors trip by trip; what is left of its last chunk is marked empty when it ends.  Chunks
+  // shrink with the queue, so that the empty positions stay a small share of it:
+  // waves x chunk <= max(waves x kStreamMinChunk, n_live / 8).
+  uint32_t chunk = kStreamMinChunk, out_next = 0, out_end = 0;  // wave-uniform
+  if (!TAIL && stream) {
+    const uint32_t per_wave = n_live / (gridDim.x * (uint32_t)(BLOCK / 64) * 8u);
+    while (chunk < kStreamMaxChunk && chunk * 2u <= per_wave) chunk *= 2u;
+  }
   const LdsScene lds = lds_stage<SPHERES ? 2u : 3u>(sc, lay, smem, threadIdx.x, BLOCK);  // the only workgroup barrier
   sc.ops_lds_offset = lds.ops_offset;
   sc.n_ops_lds = lay.n_ops;
@@ -988,6 +1019,8 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
     }
     uint32_t bounce = first_bounce;
     bool survives, deferred = false;
+    // where the path's ray and attenuation are: its queue position (streamed) or its index
+    const uint32_t slot = stream ? base + (threadIdx.x & 63u) : path;
     do {
 #ifdef RT_LANE_PROFILE
       unsigned long long tick = __builtin_readcyclecounter();
@@ -997,6 +1030,8 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
       ShadeOut so;
       so.needs_vector = false;
       so.needs_u = false;
+      V3 nb = v3(0.0, 0.0, 0.0);  // a survivor's new attenuation, its (pixel, sample) word and its time
+      double tag = 0.0, time = 0.0;
       if (valid) {
         uint32_t x = 0, y = 0;
         if (KEY_FROM_PATH) {
@@ -1006,13 +1041,12 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
           key.sample = ps.sample_base + s_local;
         }
         V3 o, d;
-        double time;
         // the first bounce makes its own camera ray
         if (FIRST) {
           camera_ray(sc, ps, x, y, key, o, d, time);
         } else {
-          double4 ro = pb.ray_o[path];
-          double4 rdv = pb.ray_d[path];
+          double4 ro = in_o[slot];
+          double4 rdv = in_d[slot];
           o = v3(ro.x, ro.y, ro.z);
           d = v3(rdv.x, rdv.y, rdv.z);
           time = ro.w;
@@ -1028,9 +1062,9 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
         RT_TICK(st, LP_T_TRAVERSE, tick);
         // ... and starts from beta = 1, L = 0
         V3 beta = v3(1.0, 1.0, 1.0);
-        double tag;  // (pixel, sample) as the spare word of the attenuation record keeps them
+        // (tag: pixel and sample as the spare word of the attenuation record keeps them)
         if (!FIRST) {
-          double4 bt = pb.beta[path];
+          double4 bt = in_beta[slot];
           beta = v3(bt.x, bt.y, bt.z);
           tag = bt.w;
           if (!KEY_FROM_PATH) {
@@ -1074,12 +1108,7 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
           }
           // depth budget: the scattered ray of the last allowed hit returns black (main.rs:121-122)
           survives = so.scattered && bounce + 1u < max_depth;
-          if (survives) {
-            // everything but the direction is known before the random vector
-            V3 nb = vmul(beta, so.attenuation);
-            pb.beta[path] = make_double4(nb.x, nb.y, nb.z, tag);
-            pb.ray_o[path] = make_double4(so.p.x, so.p.y, so.p.z, time);
-          }
+          if (survives) nb = vmul(beta, so.attenuation);
         }
         if (sc.has_lights) {
           // L += add; the first bounce also starts every path's L
@@ -1095,6 +1124,33 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
           pb.radiance[path] = make_double4(0.0 + add.x, 0.0 + add.y, 0.0 + add.z, 0.0);
         }
       }
+      // Where the survivor's state goes: in place (its index, or its position in the tail), or to the
+      // next positions of the wave's chunk of the other set, a fresh chunk when this one is used up.
+      uint32_t out_slot = slot;
+      if (!TAIL && stream) {
+        const unsigned long long m = __ballot(survives);
+        const uint32_t cnt = (uint32_t)__popcll(m);
+        if (cnt != 0u) {
+          const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull)), room = out_end - out_next;
+          if (cnt <= room) {
+            out_slot = out_next + rank;
+            out_next += cnt;
+          } else {
+            uint32_t v = 0;
+            if (lane_id() == 0) v = atomicAdd(next_count, chunk);
+            const uint32_t fresh = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+            out_slot = rank < room ? out_next + rank : fresh + (rank - room);
+            out_next = fresh + (cnt - room);
+            out_end = fresh + chunk;
+          }
+        }
+      }
+      if (survives) {
+        // everything but the direction is known before the random vector
+        out_beta[out_slot] = make_double4(nb.x, nb.y, nb.z, tag);
+        out_o[out_slot] = make_double4(so.p.x, so.p.y, so.p.z, time);
+        if (!TAIL && stream) next_live[out_slot] = path;
+      }
       RT_TICK(st, LP_T_SHADE, tick);
       {  // whole waves: the lanes look for their random vectors (and uniforms) together
         // (the wave's part of the first two stack rows is idle between traversals)
@@ -1105,7 +1161,7 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
         shade_finish(so, inside, u);
       }
       if (survives)
-        pb.ray_d[path] = make_double4(so.direction.x, so.direction.y, so.direction.z, 0.0);
+        out_d[out_slot] = make_double4(so.direction.x, so.direction.y, so.direction.z, 0.0);
       RT_TICK(st, LP_T_STORE, tick);
       if (TAIL) {
         // the same lane reads its own stores back: program order, no fence needed
@@ -1113,7 +1169,7 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
         ++bounce;
       }
     } while (TAIL && __ballot(valid) != 0ull);
-    if (!TAIL) {
+    if (!TAIL && !stream) {
       const unsigned long long mask = __ballot(survives);
       if (survives)
         stage[n_staged + (uint32_t)__popcll(mask & ((1ull << lane_id()) - 1ull))] = path;
@@ -1145,6 +1201,8 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
     trip_in_run = next_trip;
   }
   if (!TAIL && n_staged) wave_flush(stage, n_staged, next_count, next_live);
+  if (!TAIL && stream)  // the positions of the last chunk that nobody took
+    for (uint32_t i = out_next + lane_id(); i < out_end; i += 64u) next_live[i] = kNoPath;
   if (DEFER && n_deferred) wave_flush(defer_stage, n_deferred, counters + kAnyBin, pb.bins);
   if (STATS) flush_stats(st, g_stats);
 }
@@ -1319,6 +1377,10 @@ struct rt_ctx {
   // path buffers, grown on demand
   PathBuffers pb{};
   uint64_t pb_capacity = 0;
+  uint64_t pb_state = 0, pb_live = 0;  // entries of each ray/attenuation array and of each live queue
+  bool pb_alt = false;                  // the second set of ray/attenuation arrays exists
+  bool stream_on = true;                // streamed path state where nothing is deferred (MI355RT_STREAM=0: no)
+  bool max_paths_auto = false;          // max_paths came from the free device memory, not from the caller
   uint32_t pb_queues = 0;  // bin queues allocated in pb.bins
   bool solid = true;       // every texture is a SolidColor
   bool general = false;    // the scene needs the general trace kernel
@@ -1388,40 +1450,61 @@ int upload(rt_ctx* ctx, DeviceArray<T>& dst, const std::vector<S>& src) {
 void free_paths(rt_ctx* ctx) {
   PathBuffers& pb = ctx->pb;
   void* ptrs[] = {pb.ray_o, pb.ray_d, pb.beta, pb.radiance, pb.hit_item,
-                  pb.live[0], pb.live[1], pb.bins, pb.counters};
+                  pb.live[0], pb.live[1], pb.bins, pb.counters, pb.alt_o, pb.alt_d, pb.alt_beta};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   pb = PathBuffers{};
   ctx->pb_capacity = 0;
+  ctx->pb_state = ctx->pb_live = 0;
+  ctx->pb_alt = false;
   ctx->pb_queues = 0;
   ctx->counters_depth = 0;
 }
 
 // `queues`: bin queues the pipeline needs (0: fused with nothing deferred, 1: the deferred
 // queue, kBins: binned); the hit slot array exists whenever a queue does.
-int ensure_paths(rt_ctx* ctx, uint64_t capacity, uint32_t max_depth, uint32_t queues) {
+// `stream_entries`: 0, or the positions a streamed render's queues and state arrays must hold
+// (stream_positions): then the second set of state arrays exists too and a live queue is one run
+// of that many entries instead of kSubQueues regions of `capacity`.
+int ensure_paths(rt_ctx* ctx, uint64_t capacity, uint32_t max_depth, uint32_t queues, uint64_t stream_entries = 0) {
   PathBuffers& pb = ctx->pb;
-  if (capacity > ctx->pb_capacity || queues > ctx->pb_queues) {
+  const bool alt = stream_entries != 0;
+  // (held by index, a live queue is kSubQueues regions of pb.capacity entries, the largest capacity so far)
+  uint64_t state = alt ? stream_entries : capacity;
+  uint64_t live = alt ? stream_entries : std::max(capacity, ctx->pb_capacity) * kSubQueues;
+  if (capacity > ctx->pb_capacity || queues > ctx->pb_queues || state > ctx->pb_state || live > ctx->pb_live ||
+      (alt && !ctx->pb_alt)) {
     queues = std::max(queues, ctx->pb_queues);
     capacity = std::max(capacity, ctx->pb_capacity);
+    state = std::max(state, ctx->pb_state);
+    live = std::max(live, ctx->pb_live);
+    const bool want_alt = alt || ctx->pb_alt;
     uint32_t* keep_counters = pb.counters;
     uint32_t keep_depth = ctx->counters_depth;
     pb.counters = nullptr;
     free_paths(ctx);
     pb.counters = keep_counters;
     ctx->counters_depth = keep_depth;
-    RT_HIP(ctx, hipMalloc((void**)&pb.ray_o, capacity * sizeof(double4)));
-    RT_HIP(ctx, hipMalloc((void**)&pb.ray_d, capacity * sizeof(double4)));
-    RT_HIP(ctx, hipMalloc((void**)&pb.beta, capacity * sizeof(double4)));
+    RT_HIP(ctx, hipMalloc((void**)&pb.ray_o, state * sizeof(double4)));
+    RT_HIP(ctx, hipMalloc((void**)&pb.ray_d, state * sizeof(double4)));
+    RT_HIP(ctx, hipMalloc((void**)&pb.beta, state * sizeof(double4)));
+    if (want_alt) {
+      RT_HIP(ctx, hipMalloc((void**)&pb.alt_o, state * sizeof(double4)));
+      RT_HIP(ctx, hipMalloc((void**)&pb.alt_d, state * sizeof(double4)));
+      RT_HIP(ctx, hipMalloc((void**)&pb.alt_beta, state * sizeof(double4)));
+    }
     RT_HIP(ctx, hipMalloc((void**)&pb.radiance, capacity * sizeof(double4)));
-    RT_HIP(ctx, hipMalloc((void**)&pb.live[0], capacity * kSubQueues * sizeof(uint32_t)));
-    RT_HIP(ctx, hipMalloc((void**)&pb.live[1], capacity * kSubQueues * sizeof(uint32_t)));
+    RT_HIP(ctx, hipMalloc((void**)&pb.live[0], live * sizeof(uint32_t)));
+    RT_HIP(ctx, hipMalloc((void**)&pb.live[1], live * sizeof(uint32_t)));
     if (queues) {  // hits are recorded and paths queued only for a separate shade kernel
       RT_HIP(ctx, hipMalloc((void**)&pb.hit_item, capacity * sizeof(uint32_t)));
       RT_HIP(ctx, hipMalloc((void**)&pb.bins, capacity * queues * sizeof(uint32_t)));
     }
     pb.capacity = capacity;
     ctx->pb_capacity = capacity;
+    ctx->pb_state = state;
+    ctx->pb_live = live;
+    ctx->pb_alt = want_alt;
     ctx->pb_queues = queues;
   }
   if (max_depth > ctx->counters_depth) {
@@ -1736,6 +1819,16 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats, d
   uint32_t bins_present = 1u;
   for (const DMaterial& m : ctx->flat().materials) bins_present |= 2u << m.kind;
 
+  // Streamed path state (PathBuffers): the fused kernels of a scene that defers nothing, outside the
+  // no-allocation entry point (whose scratch array is laid out for state by path index).
+  const bool stream = fused && !defer && !in_scratch && ctx->stream_on;
+  const uint32_t tmax_grid = ctx->n_cus * std::max(1u, ctx->trace_blocks_per_cu);
+  // Positions a streamed pass of n paths can reach: its survivors plus what its waves leave unused
+  // of their last chunks (trace_kernel: waves x chunk <= max(waves x kStreamMinChunk, positions / 8)).
+  auto stream_positions = [&](uint64_t n) {
+    const uint64_t waves = (uint64_t)tmax_grid * (std::max(ctx->trace_block, 512u) / 64u);
+    return std::max(n + n / 7u, n + waves * kStreamMinChunk) + 1024u;
+  };
   PathBuffers scratch_pb{};
   double* accum = nullptr;
   uint32_t per_pass = 0;
@@ -1749,7 +1842,9 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats, d
       ctx->accum.n = n_pix * 3;
     }
     accum = ctx->accum.p;
-    per_pass = (uint32_t)std::min<uint64_t>(ctx->max_paths / n_pix, n_samples);
+    // (a streamed path takes about 270 bytes where one held by index takes 200: see create_single)
+    const uint64_t max_paths = stream && ctx->max_paths_auto ? std::max<uint64_t>(ctx->max_paths / 27u * 20u, n_pix) : ctx->max_paths;
+    per_pass = (uint32_t)std::min<uint64_t>(max_paths / n_pix, n_samples);
     if (per_pass == 0) per_pass = 1;
     // passes of equal size (1024 samples with room for 486 at a time: 342 + 341 + 341, not 486 + 486 + 52)
     if (n_samples) {
@@ -1771,14 +1866,16 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats, d
 
   if (!in_scratch) {
     // (device memory that turns out not to be there after all: smaller passes)
-    while ((rc = ensure_paths(ctx, n_pix * per_pass, p->max_depth, queues)) == RT_ERR_NOMEM && per_pass > 1) {
+    while ((rc = ensure_paths(ctx, n_pix * per_pass, p->max_depth, queues,
+                              stream ? stream_positions(n_pix * per_pass) : 0u)) == RT_ERR_NOMEM && per_pass > 1) {
       (void)hipGetLastError();
       free_paths(ctx);
       per_pass = (per_pass + 1) / 2;
     }
     if (rc != RT_OK) return rc;
   }
-  const PathBuffers& pb = in_scratch ? scratch_pb : ctx->pb;
+  PathBuffers pb = in_scratch ? scratch_pb : ctx->pb;
+  pb.stream = stream ? 1u : 0u;
   const uint32_t max_grid = ctx->n_cus * ctx->blocks_per_cu;
   // What each 8x8 tile's camera rays can meet, once per call (see tile_list_kernel): the fused
   // kernels' first bounce tests those few leaf slots instead of walking the hierarchy per ray.
@@ -1816,7 +1913,6 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats, d
     if (!fused)  // the fused kernel makes the camera rays in its first bounce
       raygen_kernel<<<blocks_for(ps.n_paths), kBlock, 0, ctx->stream>>>(ctx->ds, pb, ps);
     uint32_t grid = std::min(blocks_for(ps.n_paths), max_grid);
-    const uint32_t tmax_grid = ctx->n_cus * std::max(1u, ctx->trace_blocks_per_cu);
     auto trace_blocks_for = [&](uint64_t n) {
       return (uint32_t)std::min<uint64_t>((n + ctx->trace_block - 1) / ctx->trace_block, tmax_grid);
     };
@@ -1955,6 +2051,7 @@ static int create_single(int device, uint64_t max_paths_in_flight, rt_ctx** out)
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
     uint64_t fit = (uint64_t)((double)free_b * 0.7) / 200u;
     ctx->max_paths = std::min<uint64_t>(std::max<uint64_t>(fit, 1ull << 22), 1ull << 30);
+    ctx->max_paths_auto = true;
   }
   // path indices and the grid-stride loops over them are 32-bit
   if (ctx->max_paths > (1ull << 31)) {
@@ -2193,6 +2290,7 @@ static int upload_flat(rt_ctx* ctx) {
     if (const char* e = getenv("MI355RT_TAIL_PATHS")) ctx->tail_paths = (uint32_t)strtoul(e, nullptr, 10);
     if (const char* e = getenv("MI355RT_TEXTURED_TAIL")) ctx->textured_tail = atoi(e) != 0;
     if (const char* e = getenv("MI355RT_TILE_LISTS")) ctx->tile_lists_on = atoi(e) != 0;
+    if (const char* e = getenv("MI355RT_STREAM")) ctx->stream_on = atoi(e) != 0;
     ctx->blocks_per_cu = 16u;
     if (const char* e = getenv("MI355RT_BLOCKS_PER_CU"))
       ctx->blocks_per_cu = std::max(1u, (uint32_t)strtoul(e, nullptr, 10));
