@@ -351,6 +351,53 @@ def test_sphere_only_kernel_gives_the_plain_kernels_image(gpu_ctx, golden_dir, n
     assert np.array_equal(a, ref)
 
 
+@pytest.mark.parametrize("name,tail", [("book_cover", None), ("book_cover", "0"), ("material_demo", None),
+                                       ("cornell", None), ("cornell", "0"), ("emissive", None),
+                                       ("medium_demo", None), ("motion_blur", None), ("refraction", "64")])
+def test_streamed_path_state_gives_the_indexed_image(gpu_ctx, golden_dir, name, tail, monkeypatch):
+    """Scenes that defer nothing keep a path's ray and attenuation at its position in the live queue
+    (read and written densely, two sets of arrays taking turns); MI355RT_STREAM=0 keeps them at the
+    path's index.  Same paths, same draws, the same sums: the images are equal bit for bit, with the
+    tail launch, without it (every bounce a launch of its own) and with a tail of one wave."""
+    scene, g = load(golden_dir, name)
+    w, h = scene.width, scene.height
+    depth = scene.max_depth
+    if tail is not None:
+        monkeypatch.setenv("MI355RT_TAIL_PATHS", tail)
+    gpu_ctx.upload(scene)
+    a, sa = gpu_ctx.render(gpu_ctx.params(w, h, 0, 6, depth, seed=8), dtype=np.float64, stats=True)
+    c = gpu_ctx.render(gpu_ctx.params(w, h, 0, 6, depth, seed=8), dtype=np.float64)  # (the timed kernels)
+    monkeypatch.setenv("MI355RT_STREAM", "0")
+    gpu_ctx.upload(scene)
+    b, sb = gpu_ctx.render(gpu_ctx.params(w, h, 0, 6, depth, seed=8), dtype=np.float64, stats=True)
+    monkeypatch.delenv("MI355RT_STREAM")
+    if tail is not None:
+        monkeypatch.delenv("MI355RT_TAIL_PATHS")
+    gpu_ctx.upload(scene)
+    assert np.array_equal(a, b) and np.array_equal(a, c)
+    assert list(sa[:20]) == list(sb[:20])
+
+
+def test_streamed_and_indexed_renders_share_a_context(gpu_ctx, golden_dir):
+    """One context renders a large streamed pass, then a smaller pass of a scene whose textured hits
+    are deferred (state by path index, eight sub-queues as far apart as the LARGEST pass so far),
+    then the binned pipeline on the first scene: the buffers grow to what each layout needs."""
+    import pyoracle as po
+    cover, _ = load(golden_dir, "book_cover")
+    perlin, _ = load(golden_dir, "perlin")
+    cover.set_image(512, 512)
+    gpu_ctx.upload(cover)
+    big = gpu_ctx.render(gpu_ctx.params(512, 512, 0, 64, 50, seed=2), dtype=np.float64)
+    w, h = perlin.width, perlin.height
+    gpu_ctx.upload(perlin)
+    small = gpu_ctx.render(gpu_ctx.params(w, h, 0, 4, perlin.max_depth, seed=2), dtype=np.float64)
+    ref = po.Oracle(perlin.view_ptr).render(po.make_params(w, h, 0, 4, perlin.max_depth, 2), po.MODE_ITERATIVE, threads=8)
+    assert np.allclose(small, ref, rtol=1e-9, atol=1e-12)
+    gpu_ctx.upload(cover)
+    binned = gpu_ctx.render(gpu_ctx.params(512, 512, 0, 64, 50, seed=2, flags=4), dtype=np.float64)
+    assert np.array_equal(big, binned)
+
+
 @pytest.mark.parametrize("name", ["perlin", "globe", "book2", "checker_mirror"])
 def test_textured_tail_gives_the_image_of_the_deferred_kernel(gpu_ctx, golden_dir, name, monkeypatch):
     """Once few paths are left, a scene with procedural or image textures finishes them in one
