@@ -287,6 +287,48 @@ RT_DEV void stage_flush(const uint32_t* lds_buf, uint32_t* lds_count, uint32_t* 
   __syncthreads();
 }
 
+#ifndef RT_STREAM_MIN_CHUNK
+#define RT_STREAM_MIN_CHUNK 128
+#endif
+const uint32_t kStreamMinChunk = RT_STREAM_MIN_CHUNK, kStreamMaxChunk = 1024;  // (powers of two, multiples of 64)
+// Output positions of one wave in a streamed bounce (PathBuffers::stream).  The wave reserves a
+// chunk of positions at a time with one atomic and hands them to its surviving lanes call by call;
+// finish() marks what is left of its last chunk empty.  Every call is made by the whole wave.
+struct StreamOut {
+  uint32_t chunk, next, end;  // wave-uniform: chunk size; the unused part of the current chunk
+  uint32_t* counter;          // end of the position space
+  uint32_t* ids;              // path index per position, kNoPath where empty
+  RT_DEV void init(uint32_t chunk_, uint32_t* counter_, uint32_t* ids_) {
+    chunk = chunk_;
+    next = end = 0;
+    counter = counter_;
+    ids = ids_;
+  }
+  RT_DEV uint32_t take(bool survives) {  // the position of a surviving lane
+    const unsigned long long m = __ballot(survives);
+    const uint32_t cnt = (uint32_t)__popcll(m);
+    uint32_t pos = 0;
+    if (cnt != 0u) {
+      const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull)), room = end - next;
+      if (cnt <= room) {
+        pos = next + rank;
+        next += cnt;
+      } else {  // (a chunk holds a trip: one fresh chunk is enough)
+        uint32_t v = 0;
+        if (lane_id() == 0) v = atomicAdd(counter, chunk);
+        const uint32_t fresh = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+        pos = rank < room ? next + rank : fresh + (rank - room);
+        next = fresh + (cnt - room);
+        end = fresh + chunk;
+      }
+    }
+    return pos;
+  }
+  RT_DEV void finish() {
+    for (uint32_t i = next + lane_id(); i < end; i += 64u) ids[i] = kNoPath;
+  }
+};
+
 #ifdef RT_LANE_PROFILE
 __device__ unsigned long long g_lane_trips[2 * LP_COUNT];
 #endif
@@ -546,13 +588,27 @@ shade_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps, uint32_t bounce, uint3
   constexpr bool kVector = BIN == 1 + RT_MAT_LAMBERTIAN || BIN == 1 + RT_MAT_METAL ||
                            BIN == 1 + RT_MAT_ISOTROPIC || BIN == kAnyBin;
   uint32_t* counters = pb.counters + (size_t)bounce * kCounterStride;
-  uint32_t* next_live = next_live_queue(pb, bounce, blockIdx.x);
-  uint32_t* next_count = next_live_counter(pb, bounce, blockIdx.x);
+  // Streamed state (only ever with BIN == kAnyBin): a queue entry is the position the fused kernel
+  // read the path at; ray and attenuation are there, in the set of this bounce, and the survivors
+  // go to fresh positions of the other set like the fused kernel's.
+  const bool stream = BIN == kAnyBin && pb.stream != 0u;
+  uint32_t* next_live = next_live_queue(pb, bounce, stream ? 0u : blockIdx.x);
+  uint32_t* next_count = next_live_counter(pb, bounce, stream ? 0u : blockIdx.x);
+  const bool in_alt = stream && (bounce & 1u);
+  const double4* const in_o = in_alt ? pb.alt_o : pb.ray_o;
+  const double4* const in_d = in_alt ? pb.alt_d : pb.ray_d;
+  const double4* const in_beta = in_alt ? pb.alt_beta : pb.beta;
+  double4* const out_o = stream && !in_alt ? pb.alt_o : pb.ray_o;
+  double4* const out_d = stream && !in_alt ? pb.alt_d : pb.ray_d;
+  double4* const out_beta = stream && !in_alt ? pb.alt_beta : pb.beta;
+  const uint32_t* const live_in = pb.live[bounce & 1u];
   const uint32_t total = counters[BIN];
   if (blockIdx.x * kBlock >= total) return;
   const uint32_t* queue = pb.bins + (BIN == kAnyBin ? (size_t)0 : (size_t)BIN * pb.capacity);
   if (threadIdx.x == 0) s_next_count = 0;
   __syncthreads();
+  StreamOut appends;
+  appends.init(kStreamMinChunk, next_count, next_live);
   Stats st;
   if (STATS) st.clear();
   const uint32_t stride = gridDim.x * kBlock;
@@ -560,15 +616,19 @@ shade_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps, uint32_t bounce, uint3
     uint32_t i = base + threadIdx.x;
     bool valid = i < total;
     bool survives = false;
-    uint32_t path = 0;
+    uint32_t path = 0, at = 0;  // `at`: where the path's ray and attenuation are (its index, or its queue position)
     DrawKey key{ps.seed, 0u, 0u, bounce};
     ShadeOut so;
     so.needs_vector = false;
     so.needs_u = false;
+    V3 nb = v3(0.0, 0.0, 0.0);  // a survivor's new attenuation, its (pixel, sample) word and its time
+    double tag = 0.0, time = 0.0;
     if (valid) {
-      path = queue[i];
-      double4 bt = pb.beta[path];
+      at = queue[i];
+      path = stream && bounce != 0u ? live_in[at] : at;
+      double4 bt = in_beta[at];
       V3 beta = v3(bt.x, bt.y, bt.z);
+      tag = bt.w;
       if (BIN == 0) {
         // miss: the recursion returns `background` (main.rs:137-139)
         stat<STATS>(st, RT_STAT_SHADE_MISS);
@@ -576,9 +636,10 @@ shade_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps, uint32_t bounce, uint3
         V3 add = vmul(beta, v3(sc.bg));
         pb.radiance[path] = make_double4(L.x + add.x, L.y + add.y, L.z + add.z, 0.0);
       } else {
-        double4 ro = pb.ray_o[path];
-        double4 rdv = pb.ray_d[path];
-        const DPrim pr = sc.prims[pb.hit_item[path]];
+        double4 ro = in_o[at];
+        double4 rdv = in_d[at];
+        time = ro.w;
+        const DPrim pr = sc.prims[pb.hit_item[at]];
         uint32_t s_local = fastdiv(path, ps.by_pixels), local = path - s_local * ps.n_pixels;
         uint32_t x, y;
         pixel_of(ps, local, x, y);
@@ -595,23 +656,28 @@ shade_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps, uint32_t bounce, uint3
         // depth budget: the scattered ray of the last allowed hit returns black (main.rs:121-122)
         survives = so.scattered && bounce + 1u < max_depth;
         if (survives) {
-          // everything but the direction is known before the random vector
-          V3 nb = vmul(beta, so.attenuation);
-          pb.beta[path] = make_double4(nb.x, nb.y, nb.z, bt.w);  // (.w: the path's pixel and sample, see trace_kernel)
-          pb.ray_o[path] = make_double4(so.p.x, so.p.y, so.p.z, ro.w);
+          nb = vmul(beta, so.attenuation);
         } else if (BIN == kAnyBin && !sc.has_lights) {
           // the fused kernel leaves L unwritten until a path ends when nothing emits
           pb.radiance[path] = make_double4(0.0, 0.0, 0.0, 0.0);
         }
       }
     }
+    uint32_t to = at;  // where the survivor's state goes: in place, or a fresh position of the other set
+    if (stream) to = appends.take(survives);
+    if (survives) {
+      // everything but the direction is known before the random vector
+      out_beta[to] = make_double4(nb.x, nb.y, nb.z, tag);  // (.w: the path's pixel and sample, see trace_kernel)
+      out_o[to] = make_double4(so.p.x, so.p.y, so.p.z, time);
+      if (stream) next_live[to] = path;
+    }
     if (kVector) {  // whole waves: the lanes look for their random vectors together
       V3 inside = wave_rand_in_unit_sphere(survives && so.needs_vector, key, xch, 64u, st);
       shade_finish(so, inside);
     }
     if (survives)
-      pb.ray_d[path] = make_double4(so.direction.x, so.direction.y, so.direction.z, 0.0);
-    if (BIN != 0 && BIN != 1 + RT_MAT_DIFFUSE_LIGHT) {  // misses and lights end their paths
+      out_d[to] = make_double4(so.direction.x, so.direction.y, so.direction.z, 0.0);
+    if (!stream && BIN != 0 && BIN != 1 + RT_MAT_DIFFUSE_LIGHT) {  // misses and lights end their paths
       uint32_t slot = stage_append(&s_next_count, survives);
       if (survives) s_next[slot] = path;
       __syncthreads();
@@ -620,10 +686,11 @@ shade_kernel(DeviceScene sc, PathBuffers pb, PassInfo ps, uint32_t bounce, uint3
       if (n >= kFlushAt) stage_flush(s_next, &s_next_count, &s_word, next_count, next_live, n);
     }
   }
-  if (BIN != 0 && BIN != 1 + RT_MAT_DIFFUSE_LIGHT) {
+  if (!stream && BIN != 0 && BIN != 1 + RT_MAT_DIFFUSE_LIGHT) {
     uint32_t n = s_next_count;
     if (n) stage_flush(s_next, &s_next_count, &s_word, next_count, next_live, n);
   }
+  if (stream) appends.finish();
   if (STATS) flush_stats(st, g_stats);
 }
 
@@ -872,10 +939,6 @@ RT_DEV Closest closest_of_list(const DeviceScene& sc, const uint32_t* list, uint
 #ifndef RT_WAVE_FLUSH_AT
 #define RT_WAVE_FLUSH_AT 128
 #endif
-#ifndef RT_STREAM_MIN_CHUNK
-#define RT_STREAM_MIN_CHUNK 128
-#endif
-const uint32_t kStreamMinChunk = RT_STREAM_MIN_CHUNK, kStreamMaxChunk = 1024;  // (powers of two, multiples of 64)
 const uint32_t kWaveFlushAt = RT_WAVE_FLUSH_AT;
 const uint32_t kWaveStage = kWaveFlushAt + 64;
 #ifndef RT_DEFER_FLUSH_AT
@@ -950,9 +1013,12 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
   // Streamed state: where this bounce reads and writes rays and attenuations (the tail works in place).
   const bool stream = pb.stream != 0u;
   const bool in_alt = stream && (first_bounce & 1u), out_alt = stream && (TAIL ? in_alt : !in_alt);
-  const double4* const in_o = in_alt ? pb.alt_o : pb.ray_o;
-  const double4* const in_d = in_alt ? pb.alt_d : pb.ray_d;
-  const double4* const in_beta = in_alt ? pb.alt_beta : pb.beta;
+  double4* const here_o = in_alt ? pb.alt_o : pb.ray_o;
+  double4* const here_d = in_alt ? pb.alt_d : pb.ray_d;
+  double4* const here_beta = in_alt ? pb.alt_beta : pb.beta;
+  const double4* const in_o = here_o;
+  const double4* const in_d = here_d;
+  const double4* const in_beta = here_beta;
   double4* const out_o = out_alt ? pb.alt_o : pb.ray_o;
   double4* const out_d = out_alt ? pb.alt_d : pb.ray_d;
   double4* const out_beta = out_alt ? pb.alt_beta : pb.beta;
@@ -960,10 +1026,12 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
   // survivors trip by trip; what is left of its last chunk is marked empty when it ends.  Chunks
   // shrink with the queue, so that the empty positions stay a small share of it:
   // waves x chunk <= max(waves x kStreamMinChunk, n_live / 8).
-  uint32_t chunk = kStreamMinChunk, out_next = 0, out_end = 0;  // wave-uniform
-  if (!TAIL && stream) {
+  StreamOut appends;
+  {
+    uint32_t chunk = kStreamMinChunk;
     const uint32_t per_wave = n_live / (gridDim.x * (uint32_t)(BLOCK / 64) * 8u);
     while (chunk < kStreamMaxChunk && chunk * 2u <= per_wave) chunk *= 2u;
+    appends.init(chunk, next_count, next_live);
   }
   const LdsScene lds = lds_stage<SPHERES ? 2u : 3u>(sc, lay, smem, threadIdx.x, BLOCK);  // the only workgroup barrier
   sc.ops_lds_offset = lds.ops_offset;
@@ -1030,8 +1098,8 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
       ShadeOut so;
       so.needs_vector = false;
       so.needs_u = false;
-      V3 nb = v3(0.0, 0.0, 0.0);  // a survivor's new attenuation, its (pixel, sample) word and its time
-      double tag = 0.0, time = 0.0;
+      V3 nb;             // a survivor's new attenuation, its (pixel, sample) word and its time:
+      double tag, time;  // set on the way to `survives` (no initial values to keep alive until then)
       if (valid) {
         uint32_t x = 0, y = 0;
         if (KEY_FROM_PATH) {
@@ -1084,10 +1152,16 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
         } else if (!SPHERES && DEFER && (h.kind & kDeferBit)) {
           stat<STATS>(st, RT_STAT_HITS);
           deferred = true;
-          pb.ray_o[path] = make_double4(o.x, o.y, o.z, time);
-          pb.ray_d[path] = make_double4(d.x, d.y, d.z, h.t);
-          pb.hit_item[path] = h.item;
-          if (FIRST) pb.beta[path] = make_double4(1.0, 1.0, 1.0, tag);
+          // shade_kernel finds ray and attenuation where this bounce read them (the first bounce:
+          // where it would have), t in the spare word of the direction, the leaf slot beside them
+          if (FIRST) {
+            here_o[slot] = make_double4(o.x, o.y, o.z, time);
+            here_d[slot] = make_double4(d.x, d.y, d.z, h.t);
+            here_beta[slot] = make_double4(1.0, 1.0, 1.0, tag);
+          } else {
+            reinterpret_cast<double*>(here_d + slot)[3] = h.t;
+          }
+          pb.hit_item[slot] = h.item;
         } else {
           stat<STATS>(st, RT_STAT_HITS);
           RT_LP(st, LP_SHADE);
@@ -1127,24 +1201,7 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
       // Where the survivor's state goes: in place (its index, or its position in the tail), or to the
       // next positions of the wave's chunk of the other set, a fresh chunk when this one is used up.
       uint32_t out_slot = slot;
-      if (!TAIL && stream) {
-        const unsigned long long m = __ballot(survives);
-        const uint32_t cnt = (uint32_t)__popcll(m);
-        if (cnt != 0u) {
-          const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull)), room = out_end - out_next;
-          if (cnt <= room) {
-            out_slot = out_next + rank;
-            out_next += cnt;
-          } else {
-            uint32_t v = 0;
-            if (lane_id() == 0) v = atomicAdd(next_count, chunk);
-            const uint32_t fresh = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-            out_slot = rank < room ? out_next + rank : fresh + (rank - room);
-            out_next = fresh + (cnt - room);
-            out_end = fresh + chunk;
-          }
-        }
-      }
+      if (!TAIL && stream) out_slot = appends.take(survives);
       if (survives) {
         // everything but the direction is known before the random vector
         out_beta[out_slot] = make_double4(nb.x, nb.y, nb.z, tag);
@@ -1182,8 +1239,8 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
     if (DEFER) {
       const unsigned long long mask = __ballot(deferred);
       if (mask != 0ull) {
-        if (deferred)
-          defer_stage[n_deferred + (uint32_t)__popcll(mask & ((1ull << lane_id()) - 1ull))] = path;
+        if (deferred)  // (where the hit lies: the path's index or its queue position)
+          defer_stage[n_deferred + (uint32_t)__popcll(mask & ((1ull << lane_id()) - 1ull))] = slot;
         n_deferred += (uint32_t)__popcll(mask);
         if (n_deferred >= kDeferFlushAt) {
           wave_flush(defer_stage, n_deferred, counters + kAnyBin, pb.bins);
@@ -1201,8 +1258,7 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
     trip_in_run = next_trip;
   }
   if (!TAIL && n_staged) wave_flush(stage, n_staged, next_count, next_live);
-  if (!TAIL && stream)  // the positions of the last chunk that nobody took
-    for (uint32_t i = out_next + lane_id(); i < out_end; i += 64u) next_live[i] = kNoPath;
+  if (!TAIL && stream) appends.finish();
   if (DEFER && n_deferred) wave_flush(defer_stage, n_deferred, counters + kAnyBin, pb.bins);
   if (STATS) flush_stats(st, g_stats);
 }
@@ -1497,7 +1553,7 @@ int ensure_paths(rt_ctx* ctx, uint64_t capacity, uint32_t max_depth, uint32_t qu
     RT_HIP(ctx, hipMalloc((void**)&pb.live[0], live * sizeof(uint32_t)));
     RT_HIP(ctx, hipMalloc((void**)&pb.live[1], live * sizeof(uint32_t)));
     if (queues) {  // hits are recorded and paths queued only for a separate shade kernel
-      RT_HIP(ctx, hipMalloc((void**)&pb.hit_item, capacity * sizeof(uint32_t)));
+      RT_HIP(ctx, hipMalloc((void**)&pb.hit_item, state * sizeof(uint32_t)));  // (by path index or by position)
       RT_HIP(ctx, hipMalloc((void**)&pb.bins, capacity * queues * sizeof(uint32_t)));
     }
     pb.capacity = capacity;
@@ -1819,15 +1875,17 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats, d
   uint32_t bins_present = 1u;
   for (const DMaterial& m : ctx->flat().materials) bins_present |= 2u << m.kind;
 
-  // Streamed path state (PathBuffers): the fused kernels of a scene that defers nothing, outside the
-  // no-allocation entry point (whose scratch array is laid out for state by path index).
-  const bool stream = fused && !defer && !in_scratch && ctx->stream_on;
+  // Streamed path state (PathBuffers): the fused kernels, outside the no-allocation entry point
+  // (whose scratch array is laid out for state by path index).
+  const bool stream = fused && !in_scratch && ctx->stream_on;
   const uint32_t tmax_grid = ctx->n_cus * std::max(1u, ctx->trace_blocks_per_cu);
   // Positions a streamed pass of n paths can reach: its survivors plus what its waves leave unused
   // of their last chunks (trace_kernel: waves x chunk <= max(waves x kStreamMinChunk, positions / 8)).
   auto stream_positions = [&](uint64_t n) {
     const uint64_t waves = (uint64_t)tmax_grid * (std::max(ctx->trace_block, 512u) / 64u);
-    return std::max(n + n / 7u, n + waves * kStreamMinChunk) + 1024u;
+    // (the deferred shade kernel's waves append with the smallest chunk)
+    const uint64_t shade_waves = defer ? (uint64_t)ctx->n_cus * ctx->blocks_per_cu * (kBlock / 64u) : 0u;
+    return std::max(n + n / 7u, n + waves * kStreamMinChunk) + 2u * shade_waves * kStreamMinChunk + 1024u;
   };
   PathBuffers scratch_pb{};
   double* accum = nullptr;

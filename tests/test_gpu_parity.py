@@ -353,12 +353,15 @@ def test_sphere_only_kernel_gives_the_plain_kernels_image(gpu_ctx, golden_dir, n
 
 @pytest.mark.parametrize("name,tail", [("book_cover", None), ("book_cover", "0"), ("material_demo", None),
                                        ("cornell", None), ("cornell", "0"), ("emissive", None),
-                                       ("medium_demo", None), ("motion_blur", None), ("refraction", "64")])
+                                       ("medium_demo", None), ("motion_blur", None), ("refraction", "64"),
+                                       ("book2", None), ("book2", "0"), ("perlin", None), ("globe", "0"),
+                                       ("checker_mirror", None)])
 def test_streamed_path_state_gives_the_indexed_image(gpu_ctx, golden_dir, name, tail, monkeypatch):
-    """Scenes that defer nothing keep a path's ray and attenuation at its position in the live queue
-    (read and written densely, two sets of arrays taking turns); MI355RT_STREAM=0 keeps them at the
-    path's index.  Same paths, same draws, the same sums: the images are equal bit for bit, with the
-    tail launch, without it (every bounce a launch of its own) and with a tail of one wave."""
+    """The fused kernels keep a path's ray and attenuation at its position in the live queue (read
+    and written densely, two sets of arrays taking turns; a deferred textured hit is shaded from the
+    position it was found at); MI355RT_STREAM=0 keeps them at the path's index.  Same paths, same
+    draws, the same sums: the images are equal bit for bit, with the tail launch, without it
+    (every bounce a launch of its own) and with a tail of one wave."""
     scene, g = load(golden_dir, name)
     w, h = scene.width, scene.height
     depth = scene.max_depth
