@@ -87,8 +87,8 @@ struct PathBuffers {
   uint32_t* bins;     // kBins queues of `capacity` entries (binned pipeline), or the one deferred queue
   uint32_t* counters; // (max_depth) x kCounterStride
   uint64_t capacity;
-  // Streamed path state (trace_kernel, scenes that defer nothing): ray and attenuation live at the
-  // path's POSITION IN THE LIVE QUEUE, not at its index.  A bounce reads positions of the set
+  // Streamed path state (the fused pipeline): ray and attenuation live at the path's POSITION IN
+  // THE LIVE QUEUE, not at its index.  A bounce reads positions of the set
   // (bounce & 1) and writes its survivors to freshly reserved positions of the other set
   // (ray_o, ray_d, beta are set 0; alt_* set 1), so both sides are dense whatever share of
   // the pass is still alive.  Only sub-queue 0 is used; its counter is the end of the position space.
@@ -291,6 +291,13 @@ RT_DEV void stage_flush(const uint32_t* lds_buf, uint32_t* lds_count, uint32_t* 
 #define RT_STREAM_MIN_CHUNK 128
 #endif
 const uint32_t kStreamMinChunk = RT_STREAM_MIN_CHUNK, kStreamMaxChunk = 1024;  // (powers of two, multiples of 64)
+// 2: a wave of the fused kernel keeps two runs of output positions, one for survivors whose new ray
+// points up (before its random part is added) and one for the others, so that the trips of the
+// next bounce hold rays of one kind (A/B builds; measured, see the design notes).
+#ifndef RT_STREAM_CLASSES
+#define RT_STREAM_CLASSES 1
+#endif
+const uint32_t kStreamClasses = RT_STREAM_CLASSES;
 // Output positions of one wave in a streamed bounce (PathBuffers::stream).  The wave reserves a
 // chunk of positions at a time with one atomic and hands them to its surviving lanes call by call;
 // finish() marks what is left of its last chunk empty.  Every call is made by the whole wave.
@@ -1026,12 +1033,13 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
   // survivors trip by trip; what is left of its last chunk is marked empty when it ends.  Chunks
   // shrink with the queue, so that the empty positions stay a small share of it:
   // waves x chunk <= max(waves x kStreamMinChunk, n_live / 8).
-  StreamOut appends;
+  StreamOut appends, appends_down;
   {
     uint32_t chunk = kStreamMinChunk;
-    const uint32_t per_wave = n_live / (gridDim.x * (uint32_t)(BLOCK / 64) * 8u);
+    const uint32_t per_wave = n_live / (gridDim.x * (uint32_t)(BLOCK / 64) * 8u * kStreamClasses);
     while (chunk < kStreamMaxChunk && chunk * 2u <= per_wave) chunk *= 2u;
     appends.init(chunk, next_count, next_live);
+    appends_down.init(chunk, next_count, next_live);
   }
   const LdsScene lds = lds_stage<SPHERES ? 2u : 3u>(sc, lay, smem, threadIdx.x, BLOCK);  // the only workgroup barrier
   sc.ops_lds_offset = lds.ops_offset;
@@ -1201,7 +1209,15 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
       // Where the survivor's state goes: in place (its index, or its position in the tail), or to the
       // next positions of the wave's chunk of the other set, a fresh chunk when this one is used up.
       uint32_t out_slot = slot;
-      if (!TAIL && stream) out_slot = appends.take(survives);
+      if (!TAIL && stream) {
+        if (kStreamClasses == 2) {
+          const bool up = so.direction.y > 0.0;
+          const uint32_t a = appends.take(survives && up), b = appends_down.take(survives && !up);
+          out_slot = up ? a : b;
+        } else {
+          out_slot = appends.take(survives);
+        }
+      }
       if (survives) {
         // everything but the direction is known before the random vector
         out_beta[out_slot] = make_double4(nb.x, nb.y, nb.z, tag);
@@ -1258,7 +1274,10 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
     trip_in_run = next_trip;
   }
   if (!TAIL && n_staged) wave_flush(stage, n_staged, next_count, next_live);
-  if (!TAIL && stream) appends.finish();
+  if (!TAIL && stream) {
+    appends.finish();
+    if (kStreamClasses == 2) appends_down.finish();
+  }
   if (DEFER && n_deferred) wave_flush(defer_stage, n_deferred, counters + kAnyBin, pb.bins);
   if (STATS) flush_stats(st, g_stats);
 }
@@ -1885,7 +1904,7 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats, d
     const uint64_t waves = (uint64_t)tmax_grid * (std::max(ctx->trace_block, 512u) / 64u);
     // (the deferred shade kernel's waves append with the smallest chunk)
     const uint64_t shade_waves = defer ? (uint64_t)ctx->n_cus * ctx->blocks_per_cu * (kBlock / 64u) : 0u;
-    return std::max(n + n / 7u, n + waves * kStreamMinChunk) + 2u * shade_waves * kStreamMinChunk + 1024u;
+    return std::max(n + n / 7u, n + waves * kStreamClasses * kStreamMinChunk) + 2u * shade_waves * kStreamMinChunk + 1024u;
   };
   PathBuffers scratch_pb{};
   double* accum = nullptr;
