@@ -1454,7 +1454,12 @@ struct rt_ctx {
   uint64_t pb_capacity = 0;
   uint64_t pb_state = 0, pb_live = 0;  // entries of each ray/attenuation array and of each live queue
   bool pb_alt = false;                  // the second set of ray/attenuation arrays exists
-  bool stream_on = true;                // streamed path state where nothing is deferred (MI355RT_STREAM=0: no)
+  bool stream_on = true;                // streamed path state in the fused pipeline (MI355RT_STREAM=0: no)
+  // ... for passes of at least this many paths (MI355RT_STREAM_MIN_PATHS).  Smaller passes run
+  // faster by index: their launches are short enough for the chunk reservations, all on one
+  // counter, to reach the rate that word can take (a 400x225x64 render: 1.6 ms by index, 1.8 ms
+  // streamed; even at 2^24 paths, ahead from 2^25).
+  uint64_t stream_min_paths = 1ull << 24;
   bool max_paths_auto = false;          // max_paths came from the free device memory, not from the caller
   uint32_t pb_queues = 0;  // bin queues allocated in pb.bins
   bool solid = true;       // every texture is a SolidColor
@@ -1896,7 +1901,7 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats, d
 
   // Streamed path state (PathBuffers): the fused kernels, outside the no-allocation entry point
   // (whose scratch array is laid out for state by path index).
-  const bool stream = fused && !in_scratch && ctx->stream_on;
+  bool stream = fused && !in_scratch && ctx->stream_on;
   const uint32_t tmax_grid = ctx->n_cus * std::max(1u, ctx->trace_blocks_per_cu);
   // Positions a streamed pass of n paths can reach: its survivors plus what its waves leave unused
   // of their last chunks (trace_kernel: waves x chunk <= max(waves x kStreamMinChunk, positions / 8)).
@@ -1929,6 +1934,7 @@ int render_into_accum(rt_ctx* ctx, const rt_render_params* p, uint64_t* stats, d
       per_pass = (n_samples + n_passes - 1) / n_passes;
     }
   }
+  stream = stream && n_pix * per_pass >= ctx->stream_min_paths;
   *accum_out = accum;
   RT_HIP(ctx, hipMemsetAsync(accum, 0, n_pix * 3 * sizeof(double), ctx->stream));
   if (want_stats)
@@ -2368,6 +2374,7 @@ static int upload_flat(rt_ctx* ctx) {
     if (const char* e = getenv("MI355RT_TEXTURED_TAIL")) ctx->textured_tail = atoi(e) != 0;
     if (const char* e = getenv("MI355RT_TILE_LISTS")) ctx->tile_lists_on = atoi(e) != 0;
     if (const char* e = getenv("MI355RT_STREAM")) ctx->stream_on = atoi(e) != 0;
+    if (const char* e = getenv("MI355RT_STREAM_MIN_PATHS")) ctx->stream_min_paths = strtoull(e, nullptr, 10);
     ctx->blocks_per_cu = 16u;
     if (const char* e = getenv("MI355RT_BLOCKS_PER_CU"))
       ctx->blocks_per_cu = std::max(1u, (uint32_t)strtoul(e, nullptr, 10));

@@ -367,6 +367,7 @@ def test_streamed_path_state_gives_the_indexed_image(gpu_ctx, golden_dir, name, 
     depth = scene.max_depth
     if tail is not None:
         monkeypatch.setenv("MI355RT_TAIL_PATHS", tail)
+    monkeypatch.setenv("MI355RT_STREAM_MIN_PATHS", "0")  # (by default only passes of 2^24 paths and more stream)
     gpu_ctx.upload(scene)
     a, sa = gpu_ctx.render(gpu_ctx.params(w, h, 0, 6, depth, seed=8), dtype=np.float64, stats=True)
     c = gpu_ctx.render(gpu_ctx.params(w, h, 0, 6, depth, seed=8), dtype=np.float64)  # (the timed kernels)
@@ -374,6 +375,7 @@ def test_streamed_path_state_gives_the_indexed_image(gpu_ctx, golden_dir, name, 
     gpu_ctx.upload(scene)
     b, sb = gpu_ctx.render(gpu_ctx.params(w, h, 0, 6, depth, seed=8), dtype=np.float64, stats=True)
     monkeypatch.delenv("MI355RT_STREAM")
+    monkeypatch.delenv("MI355RT_STREAM_MIN_PATHS")
     if tail is not None:
         monkeypatch.delenv("MI355RT_TAIL_PATHS")
     gpu_ctx.upload(scene)
@@ -381,7 +383,7 @@ def test_streamed_path_state_gives_the_indexed_image(gpu_ctx, golden_dir, name, 
     assert list(sa[:20]) == list(sb[:20])
 
 
-def test_streamed_and_indexed_renders_share_a_context(gpu_ctx, golden_dir):
+def test_streamed_and_indexed_renders_share_a_context(gpu_ctx, golden_dir, monkeypatch):
     """One context renders a large streamed pass, then a smaller pass of a scene whose textured hits
     are deferred (state by path index, eight sub-queues as far apart as the LARGEST pass so far),
     then the binned pipeline on the first scene: the buffers grow to what each layout needs."""
@@ -390,9 +392,11 @@ def test_streamed_and_indexed_renders_share_a_context(gpu_ctx, golden_dir):
     perlin, _ = load(golden_dir, "perlin")
     cover.set_image(512, 512)
     gpu_ctx.upload(cover)
-    big = gpu_ctx.render(gpu_ctx.params(512, 512, 0, 64, 50, seed=2), dtype=np.float64)
+    big = gpu_ctx.render(gpu_ctx.params(512, 512, 0, 64, 50, seed=2), dtype=np.float64)  # (2^24 paths: streamed)
     w, h = perlin.width, perlin.height
+    monkeypatch.setenv("MI355RT_STREAM", "0")
     gpu_ctx.upload(perlin)
+    monkeypatch.delenv("MI355RT_STREAM")
     small = gpu_ctx.render(gpu_ctx.params(w, h, 0, 4, perlin.max_depth, seed=2), dtype=np.float64)
     ref = po.Oracle(perlin.view_ptr).render(po.make_params(w, h, 0, 4, perlin.max_depth, 2), po.MODE_ITERATIVE, threads=8)
     assert np.allclose(small, ref, rtol=1e-9, atol=1e-12)

@@ -20,6 +20,7 @@ from raytracer_amd.scene import HostScene  # noqa: E402
 first, count = int(sys.argv[1]), int(sys.argv[2])
 textured = "textured" in sys.argv[3:]
 wide = "wide" in sys.argv[3:]
+os.environ.setdefault("MI355RT_STREAM_MIN_PATHS", "0")  # small renders too run the streamed path state
 ctx = Context(0)
 bad = 0
 for seed in range(first, first + count):
