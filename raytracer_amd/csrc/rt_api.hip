@@ -68,13 +68,14 @@ const uint32_t kBins = 1 + RT_MAT_KINDS;  // miss + one per material kind
 const uint32_t kSubQueues = 8;
 const uint32_t kCounterStride = 32 * (1 + kSubQueues);
 const int kAnyBin = 7;                    // shade_kernel over the deferred queue: any material kind
-// [kWorkWord] of a bounce's row: how many of its live paths the waves of its trace launch have drawn
+// [kWorkWord] of a bounce's row (and of each of its sub-queue lines but the first): how many runs
+// of trips the waves of its trace launch have drawn from a stretch of the queue
 const uint32_t kWorkWord = 16;
 #ifndef RT_TRIPS_PER_GRAB
 #define RT_TRIPS_PER_GRAB 4
 #endif
-#ifndef RT_RUN_INTERLEAVE_LOG
-#define RT_RUN_INTERLEAVE_LOG 0
+#ifndef RT_WORK_SLICES
+#define RT_WORK_SLICES 8  // (at most 8: the words come from the sub-queue lines of a bounce's row)
 #endif
 
 struct PathBuffers {
@@ -1057,31 +1058,47 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
   // trip starts with one round trip to memory (the ray); a run is drawn where the last one ends
   // (drawn a trip ahead, the returned value is one more register alive across the whole trip,
   // which measured slower).
+#ifdef RT_FIRST_TRIPS_PER_GRAB
+  constexpr uint32_t kTripsPerGrab = FIRST ? RT_FIRST_TRIPS_PER_GRAB : RT_TRIPS_PER_GRAB;
+#else
   constexpr uint32_t kTripsPerGrab = RT_TRIPS_PER_GRAB;
-  // Run number r covers trips ((r >> L) * kTripsPerGrab + j) << L | (r & (2^L - 1)), j = 0 .. kTripsPerGrab - 1:
-  // with L > 0 the runs drawn at about the same time interleave trip by trip instead of each
-  // covering a stretch of the queue of its own.
-  constexpr uint32_t kRunLog = RT_RUN_INTERLEAVE_LOG;
-  uint32_t* const work = counters + kWorkWord;
+#endif
+  // One counter takes about 90 returning atomics per microsecond, and the cheap bounces of a
+  // sphere scene draw 70-85 runs of four trips in that time: the trips are split into kWorkSlices
+  // stretches with a counter each (in cache lines of their own, the spare words of the bounce's
+  // row).  A wave starts in the stretch its workgroup's index selects and moves on to the next
+  // one when a stretch has been handed out; after a full round nothing is left.
+  constexpr uint32_t kWorkSlices = RT_WORK_SLICES;
+  const uint32_t n_trips = n_live >> 6;  // (n_live is a whole number of trips)
+  auto slice_start = [&](uint32_t s) -> uint32_t { return ((n_trips * s) / kWorkSlices) << 6; };
   const uint32_t stride = gridDim.x * (uint32_t)BLOCK;
-  auto draw_run = [&]() -> uint32_t {  // index of the first ray of the run's first trip
-    uint32_t v = 0;
-    if (lane_id() == 0) v = atomicAdd(work, 1u);
-    const uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-    return ((((r >> kRunLog) * kTripsPerGrab) << kRunLog) + (r & ((1u << kRunLog) - 1u))) * 64u;
+  uint32_t slice = blockIdx.x % kWorkSlices, run_end = 0;  // wave-uniform
+  auto draw_run = [&]() -> uint32_t {  // index of the first ray of the run's first trip, or n_live
+    for (uint32_t tries = 0; tries < kWorkSlices; ++tries) {
+      uint32_t* const word = counters + (slice == 0u ? kWorkWord : 32u * (1u + slice) + kWorkWord);
+      uint32_t v = 0;
+      if (lane_id() == 0) v = atomicAdd(word, 1u);
+      const uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+      const uint32_t lo = slice_start(slice), hi = slice_start(slice + 1u);
+      const uint64_t first = (uint64_t)lo + (uint64_t)r * (kTripsPerGrab * 64u);
+      if (first < hi) {
+        run_end = (uint32_t)(first + kTripsPerGrab * 64u < hi ? first + kTripsPerGrab * 64u : hi);
+        return (uint32_t)first;
+      }
+      slice = slice + 1u == kWorkSlices ? 0u : slice + 1u;
+    }
+    return n_live;
   };
-  constexpr uint32_t kTripStep = 64u << kRunLog;  // from one trip of a run to its next
   uint32_t base = TAIL ? (uint32_t)__builtin_amdgcn_readfirstlane(
                              (int)(blockIdx.x * (uint32_t)BLOCK + (threadIdx.x & ~63u)))
                        : draw_run();
-  uint32_t trip_in_run = 0;
   uint32_t path_ahead = live.template fetch<FIRST>(base, threadIdx.x & 63u);
   while (base < n_live) {
     uint32_t path = path_ahead;
     bool valid = path != kNoPath;
     // where the next trip starts, when that is known already
-    uint32_t next_base = TAIL ? base + stride : base + kTripStep, next_trip = trip_in_run + 1u;
-    const bool draws = !TAIL && (next_trip == kTripsPerGrab || next_base >= n_live);
+    uint32_t next_base = TAIL ? base + stride : base + 64u;
+    const bool draws = !TAIL && next_base >= run_end;
     if (!draws && next_base > base) path_ahead = live.template fetch<FIRST>(next_base, threadIdx.x & 63u);
     // the first bounce: the leaf slots this trip's tile of pixels can meet, if the call made lists
     // (a trip is 64 consecutive paths of one sample = one 8x8 tile: wave-uniform)
@@ -1266,12 +1283,10 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
     }
     if (draws) {
       next_base = draw_run();
-      next_trip = 0;
       path_ahead = live.template fetch<FIRST>(next_base, threadIdx.x & 63u);
     }
     if (TAIL && next_base <= base) break;  // (32-bit wrap at the very end of the index range)
     base = next_base;
-    trip_in_run = next_trip;
   }
   if (!TAIL && n_staged) wave_flush(stage, n_staged, next_count, next_live);
   if (!TAIL && stream) {
