@@ -1058,11 +1058,7 @@ trace_kernel(DeviceScene sc, LdsLayout lay, PathBuffers pb, PassInfo ps, uint32_
   // trip starts with one round trip to memory (the ray); a run is drawn where the last one ends
   // (drawn a trip ahead, the returned value is one more register alive across the whole trip,
   // which measured slower).
-#ifdef RT_FIRST_TRIPS_PER_GRAB
-  constexpr uint32_t kTripsPerGrab = FIRST ? RT_FIRST_TRIPS_PER_GRAB : RT_TRIPS_PER_GRAB;
-#else
   constexpr uint32_t kTripsPerGrab = RT_TRIPS_PER_GRAB;
-#endif
   // One counter takes about 90 returning atomics per microsecond, and the cheap bounces of a
   // sphere scene draw 70-85 runs of four trips in that time: the trips are split into kWorkSlices
   // stretches with a counter each (in cache lines of their own, the spare words of the bounce's
