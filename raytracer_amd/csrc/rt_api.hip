@@ -294,7 +294,8 @@ RT_DEV void stage_flush(const uint32_t* lds_buf, uint32_t* lds_count, uint32_t* 
 const uint32_t kStreamMinChunk = RT_STREAM_MIN_CHUNK, kStreamMaxChunk = 1024;  // (powers of two, multiples of 64)
 // 2: a wave of the fused kernel keeps two runs of output positions, one for survivors whose new ray
 // points up (before its random part is added) and one for the others, so that the trips of the
-// next bounce hold rays of one kind (A/B builds; measured, see the design notes).
+// next bounce hold rays of one kind (A/B builds: measured slower, a trip's survivors split over
+// two runs write half-filled lines and the walk gains nothing from the class).
 #ifndef RT_STREAM_CLASSES
 #define RT_STREAM_CLASSES 1
 #endif
