@@ -2382,6 +2382,10 @@ static int upload_flat(rt_ctx* ctx) {
     // cap buys LDS for more records but measured slower (book2: 41.6 ms at 16 against 39.5 ms).
     uint32_t stack_cap = 33u;
     if (const char* e = getenv("MI355RT_STACK_CAP")) stack_cap = (uint32_t)strtoul(e, nullptr, 10);
+    // (every knob starts from its default at each upload: a variable that has been unset no longer applies)
+    ctx->tail_paths = 1u << 20;
+    ctx->textured_tail = ctx->tile_lists_on = ctx->stream_on = true;
+    ctx->stream_min_paths = 1ull << 24;
     if (const char* e = getenv("MI355RT_TAIL_PATHS")) ctx->tail_paths = (uint32_t)strtoul(e, nullptr, 10);
     if (const char* e = getenv("MI355RT_TEXTURED_TAIL")) ctx->textured_tail = atoi(e) != 0;
     if (const char* e = getenv("MI355RT_TILE_LISTS")) ctx->tile_lists_on = atoi(e) != 0;

@@ -95,14 +95,18 @@ def test_sample_ranges_add_up(gpu_ctx, golden_dir):
     assert np.abs(whole - (lo + hi)).max() <= 1e-13 * np.abs(whole).max()
 
 
-@pytest.mark.parametrize("pipeline", ["default", "binned"])
-def test_pass_size_does_not_change_the_image(gpu_ctx, golden_dir, pipeline):
-    """A small path budget splits the samples into several passes; the per-pixel sums stay in sample order."""
+@pytest.mark.parametrize("pipeline", ["default", "binned", "streamed"])
+def test_pass_size_does_not_change_the_image(gpu_ctx, golden_dir, pipeline, monkeypatch):
+    """A small path budget splits the samples into several passes; the per-pixel sums stay in sample order.
+    ("streamed": the small passes too keep their path state at queue positions, so the two sets of
+    arrays and the queues are reused pass after pass.)"""
     from raytracer_amd import abi
     from raytracer_amd.render import Context
     scene, g = load(golden_dir, "book_cover")
     w, h = scene.width, scene.height
     flags = abi.RT_FLAG_BINNED if pipeline == "binned" else 0
+    if pipeline == "streamed":
+        monkeypatch.setenv("MI355RT_STREAM_MIN_PATHS", "0")  # (read at upload; the fixture's context keeps its own setting)
     gpu_ctx.upload(scene)
     one = gpu_ctx.render(gpu_ctx.params(w, h, 0, 7, 50, seed=11, flags=flags), dtype=np.float64)
     small = Context(device=0, max_paths_in_flight=2 * w * h + 5)  # 2 samples per pass: 4 passes
@@ -403,6 +407,29 @@ def test_streamed_and_indexed_renders_share_a_context(gpu_ctx, golden_dir, monke
     gpu_ctx.upload(cover)
     binned = gpu_ctx.render(gpu_ctx.params(512, 512, 0, 64, 50, seed=2, flags=4), dtype=np.float64)
     assert np.array_equal(big, binned)
+
+
+def test_a_tuning_variable_that_is_unset_no_longer_applies(gpu_ctx, golden_dir, monkeypatch):
+    """The tuning variables are read at every upload, each from its default: MI355RT_TAIL_PATHS=0
+    makes every bounce a launch of its own, and an upload after the variable is gone brings the
+    tail launch (and the launch count) back."""
+    from raytracer_amd import abi
+    scene, g = load(golden_dir, "material_demo")
+    w, h = scene.width, scene.height
+    at = abi.STAT_NAMES.index("extend_launches")
+
+    def launches():
+        gpu_ctx.upload(scene)
+        img, st = gpu_ctx.render(gpu_ctx.params(w, h, 0, 4, scene.max_depth, seed=3), dtype=np.float64, timing=True)
+        return img, int(st[at])
+
+    a, default = launches()
+    monkeypatch.setenv("MI355RT_TAIL_PATHS", "0")
+    b, without_tail = launches()
+    monkeypatch.delenv("MI355RT_TAIL_PATHS")
+    c, again = launches()
+    assert without_tail > default and again == default
+    assert np.array_equal(a, b) and np.array_equal(a, c)
 
 
 @pytest.mark.parametrize("name", ["perlin", "globe", "book2", "checker_mirror"])
