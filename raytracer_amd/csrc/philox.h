@@ -32,6 +32,13 @@ RT_HD uint32_t mulhi32(uint32_t a, uint32_t b) {
 RT_HD u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1) {
   const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
   const uint32_t W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#if defined(__HIP_DEVICE_COMPILE__)
+  // The key is the same for every draw of a launch, so the compiler would keep all twenty round
+  // keys in scalar registers for the whole kernel (and spill other scalars to make room for them).
+  // Hidden behind this barrier they are formed again at every block, by scalar additions that cost
+  // the vector pipeline nothing.
+  asm volatile("" : "+s"(k0), "+s"(k1));
+#endif
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
