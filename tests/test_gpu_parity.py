@@ -409,6 +409,26 @@ def test_streamed_and_indexed_renders_share_a_context(gpu_ctx, golden_dir, monke
     assert np.array_equal(big, binned)
 
 
+@pytest.mark.parametrize("streamed", [False, True])
+@pytest.mark.parametrize("w,h,spp", [(2, 2, 1), (3, 5, 2), (9, 7, 3), (8, 8, 1), (64, 1 + 1, 5), (65, 3, 1)])
+def test_renders_smaller_than_a_wave(gpu_ctx, golden_dir, w, h, spp, streamed, monkeypatch):
+    """Images of a few pixels: fewer paths than a wave has lanes, queues shorter than the eight
+    stretches the work counters split them into, chunk reservations that are mostly empty; windows
+    that do and do not divide into 8x8 tiles.  The oracle's image, with the path state by index
+    and at queue positions."""
+    import pyoracle as po
+    scene, g = load(golden_dir, "material_demo")
+    scene.set_image(w, h)
+    if streamed:
+        monkeypatch.setenv("MI355RT_STREAM_MIN_PATHS", "0")
+    gpu_ctx.upload(scene)
+    got = gpu_ctx.render(gpu_ctx.params(w, h, 0, spp, scene.max_depth, seed=4), dtype=np.float64)
+    ref = po.Oracle(scene.view_ptr).render(po.make_params(w, h, 0, spp, scene.max_depth, 4), po.MODE_ITERATIVE, threads=2)
+    assert np.array_equal(got, ref)
+    ids, t, n = gpu_ctx.first_hit(w, h)
+    assert ids.shape == (h, w)
+
+
 def test_a_tuning_variable_that_is_unset_no_longer_applies(gpu_ctx, golden_dir, monkeypatch):
     """The tuning variables are read at every upload, each from its default: MI355RT_TAIL_PATHS=0
     makes every bounce a launch of its own, and an upload after the variable is gone brings the
